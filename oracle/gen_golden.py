@@ -1,0 +1,132 @@
+"""TEST INFRASTRUCTURE (container-only): record golden traces from the reference itself.
+
+Imports the reference's frozen legacy env (ref_harness.py), drives it with seeded action
+streams and writes tests/golden/<name>.npz.  The fixtures are data only: domain coordinates,
+actions, and the reference's outputs/state after every step.
+
+usage: python oracle/gen_golden.py            (rewrites every fixture)
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_harness as H  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# (fixture name, domain, stream kind, seed, T)
+TRACES = [
+    ("boundary0_uniform_s0", "boundary0", "uniform", 0, 200),     # BASELINE.json configs[0]
+    ("boundary0_biased_s1", "boundary0", "biased", 1, 700),
+    ("boundary0_uniform_s7", "boundary0", "uniform", 7, 1500),    # long enough for 100-failure truncations
+    ("boundary16_biased_s2", "boundary16", "biased", 2, 500),
+    ("boundary15_uniform_s3", "boundary15", "uniform", 3, 200),
+    ("boundary15_biased_s5", "boundary15", "biased", 5, 300),
+    ("test1_biased_s42", "test1", "biased", 42, 300),
+    ("dolphine3_biased_s0", "dolphine3", "biased", 0, 300),
+    ("random1_1_biased_s1", "random1_1", "biased", 1, 300),
+    ("basic_biased_s4", "basic", "biased", 4, 300),
+    ("star_biased_s6", "star", "biased", 6, 300),
+]
+
+
+def action_for_target(env, rule_value, target):
+    """Invert B:115-123 / D:112-137 for the env's current point environment."""
+    pe = env.current_point_environment
+    p0, p1 = pe.neighbors[3], pe.neighbors[4]
+    theta = math.atan2(p1.y - p0.y, p1.x - p0.x)
+    X = (target[0] - p0.x) / pe.base_length
+    Y = (target[1] - p0.y) / pe.base_length
+    x = math.cos(theta) * X + math.sin(theta) * Y
+    y = -math.sin(theta) * X + math.cos(theta) * Y
+    return np.array([rule_value, x, y], np.float32)
+
+
+def targeted_trace():
+    """boundary0 with hand-placed candidate points: vertex-on-ray and on-edge point-in-polygon
+    cases, a find_same_point hit, then a scripted sequence of rule -1 / +1 / 0 extractions."""
+    pts = H.domain_points("boundary0")
+    env = H.make_env(pts)
+    env.reset()
+    plan = [
+        (0.0, (3.0, 2.0)),      # ray through vertices (10,2)
+        (0.0, (3.0, 6.0)),      # on the top horizontal edge
+        (0.0, (0.0, 3.0)),      # exactly a boundary vertex
+        (0.0, (-1.0, 3.0)),     # outside, ray crosses the polygon
+        (0.0, (6.0, 0.0)),      # ray through the apex (12,0)
+        (0.0, (6.0, -6.0)),     # bottom vertex
+        (0.0, (13.0, 0.0)),     # outside right, y of apex
+        (0.0, (0.0004, 3.0)),   # find_same_point hit candidate
+        (0.0, (1.0004, 0.9996)),
+        (-1.0, (1.0, 1.0)),
+        (1.0, (1.0, 1.0)),
+        (0.0, (1.0, 1.0)),
+        (0.0, (1.0, 2.0)),
+        (0.0, (1.0, 3.0)),
+        (0.0, (2.0, 1.0)),
+        (-0.5, (1.0, 1.0)),     # thresholds are inclusive: <= -0.5 is rule -1
+        (0.5, (1.0, 1.0)),      # >= 0.5 is rule +1
+        (-0.49999, (2.0, 2.0)),
+        (0.49999, (2.0, 3.0)),
+    ]
+    # then: greedy scripted meshing -- try the ideal "square corner" point for the current reference vertex
+    actions = []
+
+    class _Rec:
+        pass
+
+    rec = _Rec()
+    rec.actions = actions
+    for rule, tgt in plan:
+        a = action_for_target(env, rule, tgt)
+        actions.append(a)
+        _, _, done, _ = env.step(a)
+        if done:
+            env.reset()
+    rng = np.random.default_rng(123)
+    for _ in range(400):
+        pe = env.current_point_environment
+        ref, right, left = pe.neighbors[3], pe.neighbors[4], pe.neighbors[2]
+        # parallelogram completion point + small jitter on the 1e-4 grid
+        tx = right.x + left.x - ref.x + float(rng.integers(-2000, 2001)) * 1e-4
+        ty = right.y + left.y - ref.y + float(rng.integers(-2000, 2001)) * 1e-4
+        rule = float(rng.choice([-1.0, 0.0, 0.0, 0.0, 1.0]))
+        a = action_for_target(env, rule, (tx, ty))
+        actions.append(a)
+        _, _, done, _ = env.step(a)
+        if done:
+            env.reset()
+    return pts, np.stack(actions).astype(np.float32)
+
+
+def save(name, tr):
+    path = os.path.join(OUT, name + ".npz")
+    n0 = tr["domain_xy"].shape[0]
+    small = np.int16 if n0 + len(tr["actions"]) < 32000 else np.int32
+    tr = dict(tr)
+    for k in ("ring_ids", "cand_ids", "reset_cand_ids"):
+        tr[k] = tr[k].astype(small)
+    np.savez_compressed(path, **tr)
+    print(f"{name}: T={len(tr['actions'])} n0={n0} valid={int(tr['valid'].sum())} done={int(tr['done'].sum())} "
+          f"complete={int((tr['done'] & tr['complete']).sum())} none={int(tr['obs_none'].sum())} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name, dom, kind, seed, T in TRACES:
+        pts = H.domain_points(dom)
+        acts = (H.uniform_actions if kind == "uniform" else H.biased_actions)(seed, T)
+        save(name, H.record_trace(pts, acts))
+    pts, acts = targeted_trace()
+    save("boundary0_targeted", H.record_trace(pts, acts))
+
+
+if __name__ == "__main__":
+    main()

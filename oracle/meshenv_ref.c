@@ -1,0 +1,824 @@
+/*
+ * oracle/meshenv_ref.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see meshenv_ref.h).
+ *
+ * Scalar restatement of the reference's BoudaryEnv step()/reset().  Line cites
+ * "B:" = v2/src/mesh_rl/legacy/boundary_env_legacy.py (== rl/boundary_env.py, +17 lines),
+ * "M:" = .../mesh_legacy.py (== general/mesh.py, +26), "C:" = .../components_legacy.py
+ * (== general/components.py, +8), "D:" = .../data_legacy.py.
+ *
+ * Numerics rules (all verified against the reference run in this container,
+ * CPython 3.10.12 + numpy 2.2.6 + glibc libm):
+ *   - build with -ffp-contract=off: Python never fuses a*b+c;
+ *   - Python `x ** 2` on a float is libm pow(x, 2.0), which is NOT always x*x
+ *     (0.085 % of random doubles differ by 1 ulp) -> SQ() calls pow();
+ *   - round(python_float, 4) is correctly-rounded decimal rounding (round4_py);
+ *     round(np.float64, 4) is rint(x*1e4)/1e4 (round4_np); round(np.float32, 4)
+ *     is the same in float32 (round4_npf).  New vertices carry np.float64
+ *     coordinates (B:123 rounds a numpy array element), domain vertices carry
+ *     Python floats/ints, and the result type of `a - b` follows NumPy
+ *     promotion, so which rounding applies depends on vertex provenance;
+ *   - np.float32 <op> python_float compares in float32 (NEP 50 weak scalars);
+ *   - builtin sum() is a plain left-to-right loop starting from int 0.
+ */
+#include "meshenv_ref.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PI 3.141592653589793 /* math.pi */
+
+typedef struct {
+    double x, y;
+} P2;
+
+struct RefEnv {
+    int n0, n;
+    P2 *ring;          /* updated_boundary.vertices */
+    int32_t *rid;      /* ring slot -> global vertex id (index in boundary.vertices) */
+    uint8_t *cand;     /* slot is in candidate_vertices */
+    double *key;       /* cached key (degrees) */
+    int64_t *stamp;    /* insertion order; larger = nearer the list head among equal keys */
+    int64_t counter;
+    int ref;           /* ring index of current_point_environment.reference_point, -1 = None */
+    double bl;         /* current_point_environment.base_length */
+    int n_elem, failed, n_vert;
+    double cur_area;
+    /* domain */
+    P2 *ring0;
+    double orig_area, min_l, crit_l;
+    /* logs */
+    int cap_v, cap_e;
+    P2 *vtab;
+    int32_t *quads;
+};
+
+/* ------------------------------------------------------------------ rounding */
+
+double meshenv_ref_round4_py(double x)
+{
+    if (!isfinite(x)) return x;
+    double ax = fabs(x);
+    double y = ax * 1e4;
+    if (y >= 4503599627370496.0) return x;
+    double e = fma(ax, 1e4, -y); /* exact: ax*1e4 == y + e */
+    double f = floor(y);
+    double t = (y - f) - 0.5;
+    double s = t + e;
+    double r;
+    if (s > 0) r = f + 1;
+    else if (s < 0) r = f;
+    else r = (fmod(f, 2.0) == 0.0) ? f : f + 1;
+    return copysign(r / 1e4, x);
+}
+
+double meshenv_ref_round4_np(double x) { return rint(x * 1e4) / 1e4; }
+
+float meshenv_ref_round4_npf(float x) { return rintf(x * 1e4f) / 1e4f; }
+
+#define round4_py meshenv_ref_round4_py
+#define round4_np meshenv_ref_round4_np
+#define round4_npf meshenv_ref_round4_npf
+
+/* ---------------------------------------------------------------- primitives */
+
+static inline double SQ(double v) { return pow(v, 2.0); } /* Python `v ** 2` */
+
+/* Point2D.distance_to, C:25-26 */
+static inline double dist(P2 a, P2 b) { return sqrt(SQ(a.x - b.x) + SQ(a.y - b.y)); }
+
+/* Vertex.to_find_clockwise_angle, C:99-108 */
+static double cw(P2 s, P2 p1, P2 p2)
+{
+    double v1x = p1.x - s.x, v1y = p1.y - s.y;
+    double v2x = p2.x - s.x, v2y = p2.y - s.y;
+    double theta = -atan2(v1x * v2y - v1y * v2x, v1x * v2x + v1y * v2y);
+    if (copysign(1.0, theta) >= 0) return round4_py(theta);
+    return round4_py(2 * PI + theta);
+}
+
+double meshenv_ref_cw(double sx, double sy, double ax, double ay, double bx, double by)
+{
+    P2 s = {sx, sy}, a = {ax, ay}, b = {bx, by};
+    return cw(s, a, b);
+}
+
+/* cross_product, C:490-491 */
+static inline double crossp(double ax, double ay, double bx, double by) { return ax * by - bx * ay; }
+
+/* Segment.straddle, C:499-524; self = (p1,p2), another = (q1,q2) */
+static int straddle(P2 p1, P2 p2, P2 q1, P2 q2)
+{
+    double s1 = round4_py(sin(cw(p1, q1, p2)));
+    double s2 = round4_py(sin(cw(p1, q2, p2)));
+    if (s1 == s2 && s2 == 0) {
+        double l1 = dist(p1, p2), l2 = dist(q1, q2);
+        if (l1 > l2) {
+            P2 m = {(p2.x + p1.x) / 2, (p2.y + p1.y) / 2};
+            double a = dist(m, q2), b = dist(m, q1);
+            if ((b < a ? b : a) <= l1 / 2) return 1;
+        } else {
+            P2 m = {(q2.x + q1.x) / 2, (q2.y + q1.y) / 2};
+            double a = dist(m, p2), b = dist(m, p1);
+            if ((b < a ? b : a) <= l2 / 2) return 1;
+        }
+        return 0;
+    }
+    double v1x = q1.x - p1.x, v1y = q1.y - p1.y;
+    double v2x = q2.x - p1.x, v2y = q2.y - p1.y;
+    double vmx = p2.x - p1.x, vmy = p2.y - p1.y;
+    return crossp(v1x, v1y, vmx, vmy) * crossp(v2x, v2y, vmx, vmy) <= 0;
+}
+
+/* Segment.is_cross, C:526-541 */
+static int is_cross(P2 a1, P2 a2, P2 b1, P2 b2) { return straddle(a1, a2, b1, b2) && straddle(b1, b2, a1, a2); }
+
+int meshenv_ref_is_cross(const double *a1, const double *a2, const double *b1, const double *b2)
+{
+    P2 A1 = {a1[0], a1[1]}, A2 = {a2[0], a2[1]}, B1 = {b1[0], b1[1]}, B2 = {b2[0], b2[1]};
+    return is_cross(A1, A2, B1, B2);
+}
+
+/* Python list index with negative wrap, for k in [-n, 2n) */
+static inline int RI(int k, int n) { return ((k % n) + n) % n; }
+
+/* ------------------------------------------------------- candidate list (a5) */
+
+/* MeshGeneration.check_boundary_point, M:228-257; returns 0 for None */
+static int check_boundary_point(const RefEnv *e, int index, double *out)
+{
+    int n = e->n;
+    P2 v = e->ring[index];
+    double w0 = 0.618, w1 = 1 - 0.618;
+    double a0 = cw(v, e->ring[(index + 1) % n], e->ring[RI(index - 1, n)]);
+    if (a0 >= PI * 0.972 || a0 == 0) return 0;
+    double sum_angle = 0;
+    sum_angle += a0 * w0;
+    double a1 = cw(v, e->ring[(index + 2) % n], e->ring[RI(index - 2, n)]);
+    sum_angle += a1 * w1;
+    *out = sum_angle * (180.0 / PI); /* math.degrees */
+    return 1;
+}
+
+/* find_reference_candidates, M:259-287: stable sort by key -> ties in ring order */
+static void find_reference_candidates(RefEnv *e)
+{
+    for (int i = 0; i < e->n; i++) {
+        double k;
+        if (check_boundary_point(e, i, &k)) {
+            e->cand[i] = 1;
+            e->key[i] = k;
+            e->stamp[i] = -(int64_t)i;
+        } else {
+            e->cand[i] = 0;
+        }
+    }
+    e->counter = 0;
+}
+
+/* add_reference_candidates, M:206-226: insert before the first entry with key >= new key */
+static void add_candidate(RefEnv *e, int pos)
+{
+    double k;
+    if (check_boundary_point(e, pos, &k)) {
+        e->cand[pos] = 1;
+        e->key[pos] = k;
+        e->stamp[pos] = ++e->counter;
+    }
+}
+
+/* find_reference_point, M:295-316: list head */
+static int select_reference(const RefEnv *e)
+{
+    int best = -1;
+    for (int i = 0; i < e->n; i++) {
+        if (!e->cand[i]) continue;
+        if (best < 0 || e->key[i] < e->key[best] ||
+            (e->key[i] == e->key[best] && e->stamp[i] > e->stamp[best]))
+            best = i;
+    }
+    return best;
+}
+
+/* -------------------------------------------------------- observation (a6) */
+
+/* PointEnvironment.get_neighbors + get_radius_points, C:1081-1090, 1192-1290;
+ * find_next_state, B:521-588 */
+static int find_next_state(RefEnv *e, float *obs)
+{
+    e->ref = select_reference(e);
+    if (e->ref < 0) {
+        memset(obs, 0, 18 * sizeof(float));
+        return 1;
+    }
+    const int n = e->n, idx = e->ref;
+    const P2 *ring = e->ring;
+    const P2 ref = ring[idx];
+    const P2 right = ring[RI(idx - 1, n)];
+    const P2 left = ring[(idx + 1) % n];
+    const double area_ratio = e->cur_area / e->orig_area;
+
+    /* neighbors = [idx+3, idx+2, idx+1, idx, idx-1, idx-2, idx-3]; C:435-444 */
+    P2 nb[7];
+    for (int i = 0; i < 4; i++) nb[i] = ring[(idx + 3 - i) % n];
+    for (int i = 1; i <= 3; i++) nb[3 + i] = ring[RI(idx - i, n)];
+    double sum = 0;
+    for (int i = 1; i < 7; i++) sum += dist(nb[i], nb[i - 1]);
+    const double bl = round4_py(sum / 6);
+    e->bl = bl;
+    const double target_length = bl * 4;
+    const double theta = cw(ref, left, right);
+
+    float r[9][2];
+    for (int i = 0; i < 9; i++) r[i][0] = r[i][1] = 1.0f;
+
+    r[0][0] = (float)((dist(ref, right) / 4) / bl);
+    r[0][1] = (float)area_ratio;
+    r[8][0] = (float)((dist(ref, left) / 4) / bl);
+    r[8][1] = (float)theta;
+    for (int i = 1; i < 3; i++) {
+        P2 pr = ring[RI(idx - i - 1, n)];
+        double a = cw(ref, pr, right);
+        r[i][0] = (float)((dist(ref, pr) / 4) / bl);
+        r[i][1] = (float)(a < PI ? a : fmax(a, 1.5 * PI) - 2 * PI);
+        P2 pl = ring[(idx + 1 + i) % n];
+        a = cw(ref, pl, right);
+        r[8 - i][0] = (float)((dist(ref, pl) / 4) / bl);
+        r[8 - i][1] = (float)fmin(a, theta + PI / 2);
+    }
+
+    P2 refp1 = {ref.x + 1, ref.y};
+    const double rot = cw(ref, right, refp1);
+    for (int i = 0; i < 3; i++) {
+        double a = ((2 * i + 1) * theta) / 6;
+        r[3 + i][1] = (float)fmin(a, theta + PI / 2);
+    }
+    /* Vertex.rotate about the origin, C:154-168 */
+    double px = target_length * cos(theta / 2), py = target_length * sin(theta / 2);
+    double qx = (0.0 + cos(rot) * px) - sin(rot) * py;
+    double qy = (0.0 + sin(rot) * px) + cos(rot) * py;
+    const P2 ps = {ref.x + qx, ref.y + qy};
+
+    double shortest = 1.0;
+    int shortest_i = 0;
+    const int i_right = RI(idx - 1, n), i_left = (idx + 1) % n;
+    for (int i = idx - 1; i > idx - n; i--) {
+        const int ii = RI(i, n);
+        const P2 v = ring[ii];
+        const double d = dist(ref, v);
+        if (ii == i_right || ii == i_left) continue;
+        const double angle = cw(ref, v, right);
+        if (angle == 0) continue;
+        const double kf = angle / (theta / 3);
+        if (kf < 3.0 && d < target_length) { /* int(kf) < 3  <=>  kf < 3 for kf >= 0 */
+            const int k = (int)kf;
+            const float cnd = (float)((d / 4) / bl);
+            if (r[k + 3][0] > cnd) {
+                r[k + 3][0] = cnd;
+                r[k + 3][1] = (float)fmin(angle, theta + PI / 2);
+            }
+        }
+        /* Segment(ref, ps).intersection_vertex(Segment(ring[i], ring[i+1])), C:657-676 */
+        const P2 a = v, b = ring[RI(i + 1, n)];
+        const double ux = ps.x - ref.x, uy = ps.y - ref.y;
+        const double wx = b.x - a.x, wy = b.y - a.y;
+        double s, h;
+        if (wy == 0) {
+            if (uy == 0) continue;
+            s = (a.y - ref.y) / uy;
+            h = (ref.x - a.x + s * ux) / wx;
+        } else if (wx == 0) {
+            if (ux == 0) continue;
+            s = (a.x - ref.x) / ux;
+            h = (ref.y - a.y + s * uy) / wy;
+        } else {
+            s = ((ref.x - a.x) / wx - (ref.y - a.y) / wy) / (uy / wy - ux / wx);
+            h = (ref.x - a.x + s * ux) / wx;
+        }
+        if (0 < s && s < 1 && 0 < h && h < 1) {
+            P2 vv = {ref.x + s * ux, ref.y + s * uy};
+            double val = (dist(ref, vv) / 4) / bl;
+            if (shortest > val) {
+                shortest = val;
+                shortest_i = i;
+            }
+        }
+    }
+    if (shortest != 1 && (float)shortest < r[4][0]) {
+        for (int i = 0; i < 3; i++) {
+            P2 v = ring[RI(i - 1 + shortest_i, n)];
+            r[3 + i][0] = (float)((dist(ref, v) / 4) / bl);
+            r[3 + i][1] = (float)cw(ref, v, right);
+        }
+    }
+    for (int i = 0; i < 9; i++) {
+        obs[2 * i] = round4_npf(r[i][0]);
+        obs[2 * i + 1] = round4_npf(r[i][1]);
+    }
+    return 0;
+}
+
+/* ----------------------------------------------------- point in polygon (a7) */
+
+static inline double round4_by(int is_np, double v) { return is_np ? round4_np(v) : round4_py(v); }
+
+/* is_point_inside_area -> calculate_crossing_segments, M:565-572, 74-128 */
+static int is_point_inside_area(const RefEnv *e, P2 p)
+{
+    const int n = e->n, n0 = e->n0;
+    const P2 *ring = e->ring;
+    const P2 far = {10000, p.y};
+    int count = 0;
+    for (int i = 0; i < n; i++) {
+        const int im1 = RI(i - 1, n), im2 = RI(i - 2, n), ip1 = (i + 1) % n;
+        const int np_i = e->rid[i] >= n0, np_im1 = e->rid[im1] >= n0;
+        const double orientation = round4_by(np_i || np_im1, ring[i].y - ring[im1].y);
+        if (orientation == 0) continue;
+        if (!is_cross(ring[i], ring[im1], p, far)) continue;
+        if (round4_np(ring[i].y - p.y) == 0) {
+            const double next_o = round4_by(e->rid[ip1] >= n0 || np_i, ring[ip1].y - ring[i].y);
+            if (next_o == 0) continue;
+            else if (next_o * orientation < 0) continue;
+            else if (orientation < 0) count += 1;
+        } else if (round4_np(ring[im1].y - p.y) == 0) {
+            const double pre_o = round4_by(np_im1 || e->rid[im2] >= n0, ring[im1].y - ring[im2].y);
+            if (pre_o == 0) continue;
+            else if (pre_o * orientation < 0) continue;
+            else if (orientation < 0) continue;
+            else count += 1;
+        } else {
+            count += 1;
+        }
+    }
+    return count % 2 != 0;
+}
+
+/* ---------------------------------------------------- quad validity (a9, a10) */
+
+/* Mesh.is_valid(0), C:738-757 + segments_crossed C:814-826 */
+static int quad_is_valid(const P2 *m)
+{
+    if (is_cross(m[0], m[1], m[2], m[3])) return 0;
+    if (is_cross(m[0], m[3], m[1], m[2])) return 0;
+    for (int i = 0; i < 4; i++) {
+        double degree = cw(m[i], m[(i + 1) % 4], m[(i + 3) % 4]);
+        if (degree > 0.99 * PI || degree < 0.01 * PI) return 0;
+    }
+    return 1;
+}
+
+/* check_intersection_with_boundary, M:536-556.  mpos[k] = ring slot of quad vertex k (-1: not in ring),
+ * r = position of the reference vertex inside the quad. */
+static int intersects_boundary(const RefEnv *e, const P2 *m, const int *mpos, int r)
+{
+    const int n = e->n;
+    const P2 *ring = e->ring;
+    const P2 ref = m[r];
+    double max_dist = -1;
+    for (int k = 0; k < 4; k++)
+        if (k != r) {
+            double d = dist(ref, m[k]);
+            if (d > max_dist) max_dist = d;
+        }
+    const P2 c0a = m[(r + 3) % 4], c0b = m[(r + 2) % 4]; /* (m[r-1], m[r-2]) */
+    const P2 c1a = m[(r + 2) % 4], c1b = m[(r + 1) % 4]; /* (m[r-2], m[r-3]) */
+#define IN_QUAD(slot) ((slot) == mpos[0] || (slot) == mpos[1] || (slot) == mpos[2] || (slot) == mpos[3])
+    for (int i = 0; i < n; i++) {
+        if (IN_QUAD(i)) continue;
+        if (!(dist(ref, ring[i]) < max_dist)) continue;
+        const int ip = RI(i - 1, n), in = (i + 1) % n;
+        for (int c = 0; c < 2; c++) {
+            const P2 ca = c ? c1a : c0a, cb = c ? c1b : c0b;
+            if (!IN_QUAD(ip) && is_cross(ca, cb, ring[i], ring[ip])) return 1;
+            if (!IN_QUAD(in) && is_cross(ca, cb, ring[i], ring[in])) return 1;
+        }
+    }
+#undef IN_QUAD
+    return 0;
+}
+
+/* ------------------------------------------------------------- reward (a12) */
+
+/* Mesh.compute_area, C:943-958 */
+static double quad_area(const P2 *m)
+{
+    double e0 = dist(m[0], m[3]), e1 = dist(m[1], m[0]), e2 = dist(m[2], m[1]), e3 = dist(m[3], m[2]);
+    double c1 = cw(m[0], m[1], m[3]);
+    double c3 = cw(m[2], m[3], m[1]);
+    return 0.5 * e0 * e1 * sin(c1) + 0.5 * e2 * e3 * sin(c3);
+}
+
+/* Mesh.get_quality('robust'), C:881-892 */
+static double quad_robust(const P2 *m)
+{
+    double mn = INFINITY;
+    for (int i = 0; i < 4; i++) {
+        double l = dist(m[(i + 3) % 4], m[i]);
+        if (l < mn) mn = l;
+    }
+    double d0 = dist(m[0], m[2]), d1 = dist(m[1], m[3]);
+    double q1 = sqrt(2.0) * mn / (d1 > d0 ? d1 : d0);
+    double amin = INFINITY, amax = -INFINITY;
+    for (int i = 0; i < 4; i++) {
+        double a = cw(m[i], m[(i + 1) % 4], m[(i + 3) % 4]);
+        if (a < amin) amin = a;
+        if (a > amax) amax = a;
+    }
+    double q2 = amin / amax;
+    return sqrt(q1 * q2);
+}
+
+/* Segment.distance(Vertex), C:678-692; segment = (p1, p2) */
+static double seg_point_distance(P2 p1, P2 p2, P2 v)
+{
+    double a = p1.x, b = p1.y;
+    double A = p2.x - p1.x, B = p2.y - p1.y;
+    double s = (A * v.x + B * v.y - B * b - A * a) / (SQ(A) + SQ(B));
+    if (0 <= s && s <= 1) {
+        P2 t = {a + s * A, b + s * B};
+        return dist(v, t);
+    } else if (s < 0) {
+        return dist(v, p1);
+    }
+    return dist(v, p2);
+}
+
+/* compute_boundary_quality(add_v), M:355-408; index = ring slot of the new vertex */
+static double boundary_quality_new(const RefEnv *e, int index)
+{
+    const int n = e->n;
+    const P2 *ring = e->ring;
+    const P2 add_v = ring[index];
+    double amin = INFINITY;
+    int have = 0;
+    for (int t = 0; t < 2; t++) {
+        int i = t == 0 ? 1 : -1;
+        int c = RI(index + i, n);
+        double angle = cw(ring[c], ring[RI(index + i + 1, n)], ring[RI(index + i - 1, n)]);
+        if (angle < PI / 3) {
+            if (angle < amin) amin = angle;
+            have = 1;
+        }
+    }
+    double q1 = have ? 3 * amin / PI : 1;
+
+    const int w0 = index, w1 = (index + 1) % n, w2 = (index + 2) % n, w3 = RI(index - 1, n), w4 = RI(index - 2, n);
+    double dst = dist(add_v, ring[w1]) + dist(add_v, ring[w3]);
+    double m_d = INFINITY;
+    int have_d = 0, prev_added = 0; /* `i - 1 in close_vs` */
+    for (int i = 0; i < n; i++) {
+        int added = 0;
+        if (!(i == w0 || i == w1 || i == w2 || i == w3 || i == w4)) {
+            if (dist(add_v, ring[i]) < dst) {
+                if (!prev_added) {
+                    added = 1;
+                    double d = seg_point_distance(ring[(i + 1) % n], ring[i], add_v);
+                    if (d < m_d) m_d = d;
+                    have_d = 1;
+                }
+            }
+        }
+        prev_added = added;
+    }
+    double targt_len = dst / 2;
+    double sum = 0;
+    for (int i = 0; i < 4; i++) sum += dist(ring[RI(index - 2 + i, n)], ring[RI(index - 1 + i, n)]);
+    double mean_dist = sum / 4;
+    double smoothness = (targt_len < mean_dist ? targt_len : mean_dist) / (targt_len > mean_dist ? targt_len : mean_dist);
+    double q2 = 1;
+    if (have_d) q2 = (m_d < 0.5 * dst) ? m_d / (0.5 * dst) : 1;
+    return pow(smoothness * q1 * q2, 1.0 / 3);
+}
+
+/* compute_ele_boundary_quality else-branch, M:418-452; t0/t1 = ring slots of the two kept quad
+ * vertices in quad order */
+static double boundary_quality_kept(const RefEnv *e, int t0, int t1)
+{
+    const int n = e->n;
+    const P2 *ring = e->ring;
+    double amin = INFINITY;
+    int have = 0;
+    int ts[2] = {t0, t1};
+    for (int k = 0; k < 2; k++) {
+        int index = ts[k];
+        double angle = cw(ring[index], ring[(index + 1) % n], ring[RI(index - 1, n)]);
+        if (angle < PI / 3) {
+            if (angle < amin) amin = angle;
+            have = 1;
+        }
+    }
+    int index = t0 < t1 ? t0 : t1;
+    double targt_len = dist(ring[t0], ring[t1]);
+    double sum = 0;
+    for (int i = 0; i < 5; i++) sum += dist(ring[RI(index - 2 + i, n)], ring[RI(index - 1 + i, n)]);
+    double mean_dist = sum / 5;
+    double smoothness = (targt_len < mean_dist ? targt_len : mean_dist) / (targt_len > mean_dist ? targt_len : mean_dist);
+    double angle_quality = have ? 3 * amin / PI : 1;
+    return pow(angle_quality * smoothness, 0.5);
+}
+
+/* get_speed_penalty, B:451-467 */
+static double speed_penalty(const RefEnv *e, double mesh_area)
+{
+    double min_area = SQ(e->min_l), critical_area = SQ(e->crit_l);
+    if (min_area <= mesh_area && mesh_area < critical_area) return (mesh_area - critical_area) / (critical_area - min_area);
+    if (mesh_area < min_area) return -1;
+    return 0;
+}
+
+/* ------------------------------------------------------------- ring edits */
+
+static void ring_delete(RefEnv *e, int pos)
+{
+    int n = e->n;
+    memmove(e->ring + pos, e->ring + pos + 1, (size_t)(n - pos - 1) * sizeof(P2));
+    memmove(e->rid + pos, e->rid + pos + 1, (size_t)(n - pos - 1) * sizeof(int32_t));
+    memmove(e->cand + pos, e->cand + pos + 1, (size_t)(n - pos - 1));
+    memmove(e->key + pos, e->key + pos + 1, (size_t)(n - pos - 1) * sizeof(double));
+    memmove(e->stamp + pos, e->stamp + pos + 1, (size_t)(n - pos - 1) * sizeof(int64_t));
+    e->n = n - 1;
+}
+
+static int ring_find(const RefEnv *e, int32_t gid)
+{
+    for (int i = 0; i < e->n; i++)
+        if (e->rid[i] == gid) return i;
+    return -1;
+}
+
+static void log_quad(RefEnv *e, const int32_t *ids)
+{
+    if (e->n_elem < e->cap_e) memcpy(e->quads + 4 * e->n_elem, ids, 4 * sizeof(int32_t));
+    e->n_elem += 1;
+}
+
+/* ---------------------------------------------------------------- API */
+
+RefEnv *meshenv_ref_create(int n0, const double *xy, double original_area, double est_min_l,
+                           double est_crit_l, int cap_new)
+{
+    RefEnv *e = (RefEnv *)calloc(1, sizeof(RefEnv));
+    e->n0 = n0;
+    e->ring = (P2 *)malloc(sizeof(P2) * n0);
+    e->ring0 = (P2 *)malloc(sizeof(P2) * n0);
+    e->rid = (int32_t *)malloc(sizeof(int32_t) * n0);
+    e->cand = (uint8_t *)malloc(n0);
+    e->key = (double *)malloc(sizeof(double) * n0);
+    e->stamp = (int64_t *)malloc(sizeof(int64_t) * n0);
+    for (int i = 0; i < n0; i++) {
+        e->ring0[i].x = xy[2 * i];
+        e->ring0[i].y = xy[2 * i + 1];
+    }
+    e->orig_area = original_area;
+    e->min_l = est_min_l;
+    e->crit_l = est_crit_l;
+    e->cap_v = n0 + cap_new;
+    e->cap_e = cap_new + n0;
+    e->vtab = (P2 *)malloc(sizeof(P2) * e->cap_v);
+    e->quads = (int32_t *)malloc(sizeof(int32_t) * 4 * e->cap_e);
+    float obs[18];
+    meshenv_ref_reset(e, obs);
+    return e;
+}
+
+void meshenv_ref_destroy(RefEnv *e)
+{
+    if (!e) return;
+    free(e->ring); free(e->ring0); free(e->rid); free(e->cand); free(e->key); free(e->stamp);
+    free(e->vtab); free(e->quads); free(e);
+}
+
+/* B:84-101 */
+int meshenv_ref_reset(RefEnv *e, float *obs)
+{
+    e->n = e->n0;
+    for (int i = 0; i < e->n0; i++) {
+        e->ring[i] = e->ring0[i];
+        e->vtab[i] = e->ring0[i];
+        e->rid[i] = i;
+    }
+    e->n_vert = e->n0;
+    e->n_elem = 0;
+    e->failed = 0;
+    e->cur_area = e->orig_area;
+    find_reference_candidates(e);
+    return find_next_state(e, obs);
+}
+
+/* B:130-280 */
+int meshenv_ref_step(RefEnv *e, const float *action, float *obs, double *reward_out, uint8_t *done_out,
+                     uint8_t *complete_out)
+{
+    int done = 0, failed = 1;
+    double reward = 0;
+    const float rule_type = action[0];
+
+    /* action_2_point -> detransformation, B:633-642, B:115-123, D:112-137.
+     * p0 = neighbors[3] = ref, p1 = neighbors[4] = ring[ref-1] of the last observation. */
+    P2 new_point = {0, 0};
+    const int index = e->ref;
+    if (index >= 0) {
+        const int n = e->n;
+        const double px = (double)round4_npf(action[1]);
+        const double py = (double)round4_npf(action[2]);
+        const P2 p0 = e->ring[index], p1 = e->ring[RI(index - 1, n)];
+        const double theta = 2 * PI - atan2(p1.y - p0.y, p1.x - p0.x);
+        double ox = cos(theta) * px + sin(theta) * py;
+        double oy = -sin(theta) * px + cos(theta) * py;
+        ox *= e->bl;
+        oy *= e->bl;
+        ox += p0.x;
+        oy += p0.y;
+        new_point.x = round4_np(ox);
+        new_point.y = round4_np(oy);
+    }
+
+    if (index < 0) {
+        /* the reference would have crashed one call earlier (obs None); keep the env inert */
+        reward = -1;
+    } else if (e->n <= 5) {
+        reward = 10; /* B:158-160 */
+        done = 1;
+    } else {
+        const int n = e->n;
+        P2 m[4];
+        int mpos[4];
+        int have_mesh = 1, rule, r, new_vertex = 0;
+        if (rule_type <= -0.5f) {
+            rule = -1;
+        } else if (rule_type >= 0.5f) {
+            rule = 1;
+        } else {
+            rule = 0;
+            if (is_point_inside_area(e, new_point)) {
+                int same = -1; /* find_same_point, B:616-619 */
+                for (int i = 0; i < n; i++)
+                    if (dist(e->ring[i], new_point) < 0.001) {
+                        same = i;
+                        break;
+                    }
+                if (same >= 0) rule = -1; /* existing point: the rule -1 quad, B:185-192 */
+                else new_vertex = 1;
+            } else {
+                reward += e->n_elem ? -1.0 / e->n_elem : -1;
+                have_mesh = 0;
+            }
+        }
+        if (have_mesh) {
+            if (new_vertex) { /* [new, i-1, i, i+1], B:194-199 */
+                mpos[0] = -1; mpos[1] = RI(index - 1, n); mpos[2] = index; mpos[3] = (index + 1) % n;
+                r = 2;
+            } else if (rule == -1) { /* [i-1, i, i+1, i+2], B:164-170 */
+                mpos[0] = RI(index - 1, n); mpos[1] = index; mpos[2] = (index + 1) % n; mpos[3] = (index + 2) % n;
+                r = 1;
+            } else { /* [i-2, i-1, i, i+1], B:173-179 */
+                mpos[0] = RI(index - 2, n); mpos[1] = RI(index - 1, n); mpos[2] = index; mpos[3] = (index + 1) % n;
+                r = 2;
+            }
+            for (int k = 0; k < 4; k++) m[k] = mpos[k] < 0 ? new_point : e->ring[mpos[k]];
+
+            if (quad_is_valid(m) && !intersects_boundary(e, m, mpos, r)) {
+                int32_t qids[4];
+                for (int k = 0; k < 4; k++) qids[k] = mpos[k] < 0 ? e->n_vert : e->rid[mpos[k]];
+                log_quad(e, qids); /* generated_meshes.append, B:209 */
+
+                /* update_boundary, M:601-669 */
+                double b_reward;
+                if (new_vertex) {
+                    const int id = index;
+                    e->ring[id] = new_point;
+                    e->rid[id] = e->n_vert;
+                    e->cand[id] = 0;
+                    if (e->n_vert < e->cap_v) e->vtab[e->n_vert] = new_point;
+                    e->n_vert += 1;
+                    int pos[4] = {(id + 1) % n, RI(id - 1, n), (id + 2) % n, RI(id - 2, n)};
+                    for (int k = 0; k < 4; k++) e->cand[pos[k]] = 0;
+                    for (int k = 0; k < 4; k++) add_candidate(e, pos[k]);
+                    b_reward = boundary_quality_new(e, id);
+                } else {
+                    int32_t keep0 = e->rid[mpos[0]], keep1 = e->rid[mpos[3]];
+                    int32_t rem0 = e->rid[mpos[1]], rem1 = e->rid[mpos[2]];
+                    ring_delete(e, ring_find(e, rem0));
+                    ring_delete(e, ring_find(e, rem1));
+                    const int nn = e->n;
+                    int t0 = ring_find(e, keep0), t1 = ring_find(e, keep1);
+                    int id = t0 > t1 ? t0 : t1;
+                    int pos[4] = {id % nn, RI(id - 1, nn), (id + 1) % nn, RI(id - 2, nn)};
+                    for (int k = 0; k < 4; k++) e->cand[pos[k]] = 0;
+                    for (int k = 0; k < 4; k++) add_candidate(e, pos[k]);
+                    b_reward = boundary_quality_kept(e, t0, t1);
+                }
+                const double mesh_area = quad_area(m);
+                e->cur_area -= mesh_area;
+                /* get_quality(mesh, 2), M:1759-1766 */
+                const double e_reward = quad_robust(m);
+                const double quality = e_reward + 1 * (b_reward - 1);
+                reward += quality + speed_penalty(e, mesh_area);
+                failed = 0;
+                if (e->n <= 5) { /* B:249-261 */
+                    reward += 10;
+                    done = 1;
+                    if (e->n == 4) log_quad(e, e->rid);
+                }
+            } else {
+                reward += e->n_elem ? -1.0 / e->n_elem : -1; /* B:265 */
+            }
+        }
+    }
+    int is_complete = 1;
+    int none = find_next_state(e, obs);
+    if (!failed) {
+        e->failed = 0;
+    } else {
+        e->failed += 1;
+        if (e->failed >= 100) {
+            done = 1;
+            is_complete = 0;
+        }
+    }
+    *reward_out = reward;
+    *done_out = (uint8_t)done;
+    *complete_out = (uint8_t)is_complete;
+    return none;
+}
+
+int meshenv_ref_ring_len(const RefEnv *e) { return e->n; }
+
+void meshenv_ref_get_ring(const RefEnv *e, int32_t *ids, double *xy)
+{
+    for (int i = 0; i < e->n; i++) {
+        if (ids) ids[i] = e->rid[i];
+        if (xy) {
+            xy[2 * i] = e->ring[i].x;
+            xy[2 * i + 1] = e->ring[i].y;
+        }
+    }
+}
+
+int meshenv_ref_get_candidates(const RefEnv *e, int32_t *ids, double *keys)
+{
+    /* selection sort into (key asc, stamp desc) order: O(n^2), test-only */
+    int n = e->n, m = 0;
+    uint8_t *used = (uint8_t *)calloc((size_t)n, 1);
+    for (;;) {
+        int best = -1;
+        for (int i = 0; i < n; i++) {
+            if (!e->cand[i] || used[i]) continue;
+            if (best < 0 || e->key[i] < e->key[best] || (e->key[i] == e->key[best] && e->stamp[i] > e->stamp[best]))
+                best = i;
+        }
+        if (best < 0) break;
+        used[best] = 1;
+        ids[m] = e->rid[best];
+        keys[m] = e->key[best];
+        m++;
+    }
+    free(used);
+    return m;
+}
+
+int meshenv_ref_ref_id(const RefEnv *e) { return e->ref < 0 ? -1 : e->rid[e->ref]; }
+
+void meshenv_ref_get_scalars(const RefEnv *e, int32_t *n_elem, int32_t *failed_num, int32_t *n_vert,
+                             double *current_area)
+{
+    *n_elem = e->n_elem;
+    *failed_num = e->failed;
+    *n_vert = e->n_vert;
+    *current_area = e->cur_area;
+}
+
+void meshenv_ref_get_elements(const RefEnv *e, int32_t *quads, double *vertex_xy, int32_t *n_elem,
+                              int32_t *n_vert)
+{
+    int ne = e->n_elem < e->cap_e ? e->n_elem : e->cap_e;
+    int nv = e->n_vert < e->cap_v ? e->n_vert : e->cap_v;
+    if (quads) memcpy(quads, e->quads, sizeof(int32_t) * 4 * (size_t)ne);
+    if (vertex_xy)
+        for (int i = 0; i < nv; i++) {
+            vertex_xy[2 * i] = e->vtab[i].x;
+            vertex_xy[2 * i + 1] = e->vtab[i].y;
+        }
+    *n_elem = ne;
+    *n_vert = nv;
+}
+
+void meshenv_ref_step_batch(RefEnv **envs, int n, const float *actions, float *obs, double *reward,
+                            uint8_t *done, uint8_t *is_complete, float *terminal_obs, int auto_reset,
+                            int threads)
+{
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int i = 0; i < n; i++) {
+        meshenv_ref_step(envs[i], actions + 3 * i, obs + 18 * i, reward + i, done + i, is_complete + i);
+        if (done[i] && auto_reset) {
+            if (terminal_obs) memcpy(terminal_obs + 18 * i, obs + 18 * i, 18 * sizeof(float));
+            meshenv_ref_reset(envs[i], obs + 18 * i);
+        }
+    }
+}

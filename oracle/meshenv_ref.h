@@ -1,0 +1,73 @@
+/*
+ * oracle/meshenv_ref.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar CPU restatement (plain C, host libm) of the reference's
+ * element-extraction step()/reset() hot path (rl/boundary_env.py + general/mesh.py +
+ * general/components.py + general/data.py; line cites are in meshenv_ref.c and
+ * refer to the frozen, logic-identical snapshot v2/src/mesh_rl/legacy/).
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this file
+ * bit-for-bit (obs, reward, topology, candidate list) against traces recorded
+ * from the reference itself (oracle/gen_golden.py -> tests/golden/ npz files).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product library (libmeshenv_hip.so) never links,
+ * loads or calls anything declared here.
+ */
+#ifndef MESHENV_REF_H
+#define MESHENV_REF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct RefEnv RefEnv;
+
+/* One environment over one domain polygon (clockwise ring, n0 vertices, xy = [x0,y0,x1,y1,...]).
+ * original_area / est_min_l / est_crit_l are the domain constants the reference computes in
+ * __init__/reset (Boundary2D.poly_area, MeshGeneration.estimate_area_range); the host computes
+ * them (reinforcementlearning4meshgeneration_amd/domains.py) and passes them in.
+ * cap_new = capacity of the new-vertex / element logs. */
+RefEnv *meshenv_ref_create(int n0, const double *xy, double original_area, double est_min_l,
+                           double est_crit_l, int cap_new);
+void meshenv_ref_destroy(RefEnv *e);
+
+/* reset(): rl/boundary_env.py:67-84.  Writes obs[18]; returns 1 if the reference would return None. */
+int meshenv_ref_reset(RefEnv *e, float *obs);
+
+/* step(action[3]): rl/boundary_env.py:113-263.  Returns 1 if obs is None in the reference. */
+int meshenv_ref_step(RefEnv *e, const float *action, float *obs, double *reward, uint8_t *done,
+                     uint8_t *is_complete);
+
+/* state readout for parity tests */
+int meshenv_ref_ring_len(const RefEnv *e);
+void meshenv_ref_get_ring(const RefEnv *e, int32_t *ids, double *xy);
+/* candidate list in the reference's list order: (key asc, insertion desc) */
+int meshenv_ref_get_candidates(const RefEnv *e, int32_t *ids, double *keys);
+int meshenv_ref_ref_id(const RefEnv *e);
+void meshenv_ref_get_scalars(const RefEnv *e, int32_t *n_elem, int32_t *failed_num, int32_t *n_vert,
+                             double *current_area);
+/* vertex_xy[n_vert*2] (initial ring first, then new vertices), quads[n_elem*4] global ids */
+void meshenv_ref_get_elements(const RefEnv *e, int32_t *quads, double *vertex_xy, int32_t *n_elem,
+                              int32_t *n_vert);
+
+/* batch driver used by tests and by bench.py's cpu_baseline leg: steps n envs once each,
+ * auto-resetting finished ones when auto_reset != 0 (obs then holds the reset obs and
+ * terminal_obs, if non-NULL, the last obs).  threads > 1 uses OpenMP when compiled with it. */
+void meshenv_ref_step_batch(RefEnv **envs, int n, const float *actions, float *obs, double *reward,
+                            uint8_t *done, uint8_t *is_complete, float *terminal_obs, int auto_reset,
+                            int threads);
+
+/* primitives exported for unit tests */
+double meshenv_ref_round4_py(double x);
+double meshenv_ref_round4_np(double x);
+float meshenv_ref_round4_npf(float x);
+double meshenv_ref_cw(double sx, double sy, double ax, double ay, double bx, double by);
+int meshenv_ref_is_cross(const double *a1, const double *a2, const double *b1, const double *b2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

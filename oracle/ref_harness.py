@@ -1,0 +1,203 @@
+"""TEST INFRASTRUCTURE (container-only): import shim for the reference's frozen legacy env.
+
+This module exists only to (1) validate oracle/meshenv_ref.c against the real
+reference and (2) generate the golden fixtures under tests/golden/.  It reads
+/root/reference at run time, so it is never used on the GPU box and never by
+the product path.  Nothing here is shipped behaviour.
+
+The stubbing mirrors the reference's own technique for running the env without
+the RL stack (/root/reference/v2/tests/mesh_rl/test_boundary_env_equiv.py:17-151):
+`gym` and `stable_baselines3.common.env_checker` are replaced by empty module
+objects, and the `mesh_rl` / `mesh_rl.legacy` package __init__ files (which pull
+gymnasium + SB3) are skipped by pre-registering bare packages with __path__ set.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REFERENCE_ROOT = os.environ.get("MESHENV_REFERENCE_ROOT", "/root/reference")
+_SRC = os.path.join(REFERENCE_ROOT, "v2", "src")
+
+# action box of rl/boundary_env.py:27
+ACTION_LOW = np.array([-1.0, -1.5, 0.0])
+ACTION_HIGH = np.array([1.0, 1.5, 1.5])
+
+# the 30 literal vertices of general/polygon.py:79-83 (boundary(index=0)); data, not code
+BOUNDARY0 = [(0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6),
+             (1, 6), (2, 6), (3, 6), (4, 6), (5, 6), (6, 6),
+             (7, 5), (8, 4), (9, 3), (10, 2), (11, 1), (12, 0),
+             (11, -1), (10, -2), (9, -3), (8, -4), (7, -5), (6, -6),
+             (5, -5), (4, -4), (3, -3), (2, -2), (1, -1), (0, 0)]
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(_SRC, "mesh_rl", "legacy"))
+
+
+_loaded = None
+
+
+def load_reference():
+    """Import the legacy env; returns (BoudaryEnvLegacy, Vertex, Segment, Boundary2D)."""
+    global _loaded
+    if _loaded is not None:
+        return _loaded
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    if _SRC not in sys.path:
+        sys.path.insert(0, _SRC)
+    for name, sub in (("mesh_rl", "mesh_rl"), ("mesh_rl.legacy", os.path.join("mesh_rl", "legacy"))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(_SRC, sub)]
+            sys.modules[name] = m
+    if "gym" not in sys.modules:
+        gym = types.ModuleType("gym")
+        spaces = types.ModuleType("gym.spaces")
+
+        class _Box:
+            def __init__(self, low, high, shape=None, dtype=None):
+                if shape is not None:
+                    shape = tuple(shape)
+                    self.low = np.full(shape, low, dtype=np.float32)
+                    self.high = np.full(shape, high, dtype=np.float32)
+                else:
+                    self.low = np.array(low, dtype=np.float32)
+                    self.high = np.array(high, dtype=np.float32)
+                    shape = self.low.shape
+                self.shape = shape
+                self.dtype = dtype or np.float32
+
+        gym.Env = type("Env", (), {})
+        spaces.Box = _Box
+        gym.spaces = spaces
+        sys.modules.update({"gym": gym, "gym.spaces": spaces})
+    if "stable_baselines3" not in sys.modules:
+        sb3 = types.ModuleType("stable_baselines3")
+        common = types.ModuleType("stable_baselines3.common")
+        ec = types.ModuleType("stable_baselines3.common.env_checker")
+        ec.check_env = lambda *a, **k: None
+        sys.modules.update({"stable_baselines3": sb3, "stable_baselines3.common": common,
+                            "stable_baselines3.common.env_checker": ec})
+    from mesh_rl.legacy.boundary_env_legacy import BoudaryEnvLegacy  # noqa: E402
+    from mesh_rl.legacy.components_legacy import Vertex, Segment, Boundary2D  # noqa: E402
+    _loaded = (BoudaryEnvLegacy, Vertex, Segment, Boundary2D)
+    return _loaded
+
+
+def domain_points(name: str):
+    """Python-typed coordinates exactly as the reference builds them.
+
+    'boundary0' -> int literals (general/polygon.py:79-83);
+    anything else -> ui/domains/<name>.json, first line, each coord / 100
+    (general/polygon.py:110-117).
+    """
+    if name == "boundary0":
+        return [(x, y) for x, y in BOUNDARY0]
+    path = os.path.join(REFERENCE_ROOT, "ui", "domains", name + ".json")
+    with open(path, "r") as fr:
+        verts = json.loads(fr.readline())
+    return [(p[0] / 100, p[1] / 100) for p in verts]
+
+
+def make_env(points):
+    Env, Vertex, Segment, Boundary2D = load_reference()
+    vs = [Vertex(x, y) for x, y in points]
+    for i in range(len(vs)):           # as connect_vertices, general/mesh.py:1926-1930
+        s = Segment(vs[i - 1], vs[i])
+        vs[i - 1].assign_segment(s)
+        vs[i].assign_segment(s)
+    return Env(Boundary2D(vs))
+
+
+def uniform_actions(seed: int, T: int) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    return rng.uniform(ACTION_LOW, ACTION_HIGH, size=(T, 3)).astype(np.float32)
+
+
+def biased_actions(seed: int, T: int) -> np.ndarray:
+    """Half the actions are drawn from a sub-box that makes valid extractions likely
+    (a[1] in [0.2,1], a[2] in [0.3,1.2]); rule type spread over all three rules."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(ACTION_LOW, ACTION_HIGH, size=(T, 3))
+    pick = rng.random(T) < 0.5
+    b = np.stack([rng.uniform(-1, 1, T), rng.uniform(0.2, 1.0, T), rng.uniform(0.3, 1.2, T)], axis=1)
+    a[pick] = b[pick]
+    return a.astype(np.float32)
+
+
+def record_trace(points, actions: np.ndarray, auto_reset: bool = True) -> dict:
+    """Drive the reference env with `actions` and record everything parity needs."""
+    env = make_env(points)
+    n0 = len(points)
+    T = len(actions)
+    reset_obs = env.reset()
+    consts = dict(
+        original_area=float(env.original_area),
+        average_edge_length=float(env.average_edge_length),
+        est_min_l=float(env.estimated_area_range[0]),
+        est_crit_l=float(env.estimated_area_range[1]),
+    )
+
+    def ids_of(vlist):
+        table = {id(v): k for k, v in enumerate(env.boundary.vertices)}
+        return [table[id(v)] for v in vlist]
+
+    def snapshot_cands():
+        cv = env.candidate_vertices
+        return ids_of([c[0] for c in cv]), [float(c[1]) for c in cv]
+
+    out = dict(
+        obs=np.zeros((T, 18), np.float32), obs_none=np.zeros(T, np.uint8),
+        reward=np.zeros(T, np.float64), done=np.zeros(T, np.uint8), complete=np.zeros(T, np.uint8),
+        ring_len=np.zeros(T, np.int32), ring_ids=np.full((T, n0), -1, np.int32),
+        ref_id=np.full(T, -1, np.int32), n_elem=np.zeros(T, np.int32), failed_num=np.zeros(T, np.int32),
+        current_area=np.zeros(T, np.float64), new_xy=np.full((T, 2), np.nan, np.float64),
+        n_cand=np.zeros(T, np.int32), cand_ids=np.full((T, n0), -1, np.int32),
+        cand_keys=np.full((T, n0), np.nan, np.float64), valid=np.zeros(T, np.uint8),
+    )
+    r_ids, r_keys = snapshot_cands()
+    out["reset_cand_ids"] = np.array(r_ids, np.int32)
+    out["reset_cand_keys"] = np.array(r_keys, np.float64)
+    out["reset_ref_id"] = np.int32(ids_of([env.current_point_environment.reference_point])[0])
+    for t in range(T):
+        nverts_before = len(env.boundary.vertices)
+        nelem_before = len(env.generated_meshes)
+        obs, rew, done, info = env.step(actions[t])
+        if obs is None:
+            out["obs_none"][t] = 1
+        else:
+            out["obs"][t] = obs
+        out["reward"][t] = rew
+        out["done"][t] = done
+        out["complete"][t] = info["is_complete"]
+        ring = ids_of(env.updated_boundary.vertices)
+        out["ring_len"][t] = len(ring)
+        out["ring_ids"][t, :len(ring)] = ring
+        out["ref_id"][t] = ids_of([env.current_point_environment.reference_point])[0]
+        out["n_elem"][t] = len(env.generated_meshes)
+        out["failed_num"][t] = env.failed_num
+        out["current_area"][t] = env.current_area
+        out["valid"][t] = len(env.generated_meshes) > nelem_before
+        if len(env.boundary.vertices) > nverts_before:
+            v = env.boundary.vertices[-1]
+            out["new_xy"][t] = (v.x, v.y)
+        cids, ckeys = snapshot_cands()
+        out["n_cand"][t] = len(cids)
+        # duplicates can push the list past n0 on tiny rings; clip for storage
+        m = min(len(cids), n0)
+        out["cand_ids"][t, :m] = cids[:m]
+        out["cand_keys"][t, :m] = ckeys[:m]
+        if done and auto_reset:
+            env.reset()
+    out.update(
+        domain_xy=np.array(points, np.float64), actions=actions, reset_obs=reset_obs.astype(np.float32),
+        consts=np.array([consts["original_area"], consts["average_edge_length"],
+                         consts["est_min_l"], consts["est_crit_l"]], np.float64),
+        auto_reset=np.uint8(auto_reset),
+    )
+    return out

@@ -1,0 +1,185 @@
+"""Domain polygons and the per-domain constants the reference computes in __init__/reset.
+
+Host-side (Python) part of the hot path's input format:
+
+* ``boundary(index)``        -- the built-in domains of general/polygon.py:76-108 (literal vertex data)
+* ``read_polygon(path)``     -- ui/domains/*.json loader, general/polygon.py:110-117 (first line of the
+                               file is ``[[x, y], ...]`` in pixels; coordinates are divided by 100)
+* ``generate_polygon(...)``  -- restatement of ui/GenerateRandomPolygon.py:5-49 (config 5)
+* ``domain_constants(pts)``  -- original_area (general/components.py:477-479), average_edge_length
+                               (components.py:442-447) and estimate_area_range (general/mesh.py:679-692)
+
+Everything ``BoudaryEnv.reset()`` computes besides these three is recomputed on the device by the
+reset kernel.  The constants are computed here with the same Python/NumPy expressions the reference
+uses (``**`` is libm pow, ``sum`` is a left-to-right loop, ``np.dot`` is BLAS), so that they are the
+reference's numbers and not a re-derivation.
+"""
+from __future__ import annotations
+
+import json
+import math
+import random
+from dataclasses import dataclass
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+Point = Tuple[float, float]
+
+# general/polygon.py:79-83 -- data
+_BOUNDARY_0 = [(0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6),
+               (1, 6), (2, 6), (3, 6), (4, 6), (5, 6), (6, 6),
+               (7, 5), (8, 4), (9, 3), (10, 2), (11, 1), (12, 0),
+               (11, -1), (10, -2), (9, -3), (8, -4), (7, -5), (6, -6),
+               (5, -5), (4, -4), (3, -3), (2, -2), (1, -1), (0, 0)]
+# general/polygon.py:84-93
+_BOUNDARY_1 = [(0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (0, 7), (0, 8), (0, 9), (0, 10), (0, 11),
+               (1, 11), (2, 11), (3, 11), (4, 11), (5, 11), (6, 11), (7, 11), (8, 11),
+               (9, 11), (8, 10), (7.5, 9), (7, 8), (6.5, 7), (6, 6), (6.5, 5.5),
+               (7, 5), (8, 4), (9, 3), (10, 2), (11, 1), (12, 0),
+               (11, -1), (10, -2), (9, -3), (8, -4), (7, -5), (6, -6),
+               (5, -5), (4, -4), (3, -3), (2, -2), (1, -1), (0, 0)]
+# general/polygon.py:94-100
+_BOUNDARY_2 = [(0, 1), (0, 2), (0, 3), (0, 4), (1, 4), (2, 4), (3, 4), (4, 4),
+               (5, 4), (5, 3), (5, 2), (5, 1), (5, 0), (5, -1), (5, -2), (5, -3),
+               (5, -4), (5, -5), (5, -6), (5, -7), (4, -7), (3, -7), (2, -7), (1, -7),
+               (0, -7), (0, -6), (0, -5), (0, -4), (1, -4), (2, -4), (3, -4), (4, -4),
+               (4, -3), (4, -2), (4, -1), (4, 0), (3, 0), (2, 0), (1, 0), (0, 0)]
+# general/polygon.py:101-105
+_BOUNDARY_M1 = [(0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6),
+                (1, 6), (2, 6), (3, 6), (4, 6), (5, 6), (6, 6),
+                (6, 5), (6, 4), (6, 3), (6, 2), (6, 1), (6, 0),
+                (5, 0), (4, 0), (3, 0), (2, 0), (1, 0), (0, 0)]
+
+
+def boundary(index: int = 0) -> List[Point]:
+    """Vertex list of general/polygon.py::boundary(index) (clockwise)."""
+    table = {0: _BOUNDARY_0, 1: _BOUNDARY_1, 2: _BOUNDARY_2, -1: _BOUNDARY_M1}
+    if index not in table:
+        raise ValueError(f"boundary(): unknown index {index}")
+    return list(table[index])
+
+
+def read_polygon(filename) -> List[Point]:
+    """general/polygon.py:110-117: first line of the file is the JSON vertex list; coords / 100."""
+    with open(filename, "r") as fr:
+        vertices = json.loads(fr.readline())
+    return [(p[0] / 100, p[1] / 100) for p in vertices]
+
+
+def signed_area2(points: Sequence[Point]) -> float:
+    """Twice the shoelace area; negative for the clockwise rings the reference works on."""
+    s = 0.0
+    n = len(points)
+    for i in range(n):
+        x0, y0 = points[i - 1]
+        x1, y1 = points[i]
+        s += x0 * y1 - x1 * y0
+    return s
+
+
+def _clip(x, lo, hi):
+    if lo > hi:
+        return x
+    return lo if x < lo else hi if x > hi else x
+
+
+def generate_polygon(ctr_x=250, ctr_y=250, ave_radius=100, irregularity=0.55, spikeyness=0.7,
+                     num_verts=16, rng: random.Random | None = None) -> List[Tuple[int, int]]:
+    """ui/GenerateRandomPolygon.py:5-49 with an explicit ``random.Random`` (pixel coords, CCW)."""
+    rng = rng or random
+    irregularity = _clip(irregularity, 0, 1) * 2 * math.pi / num_verts
+    spikeyness = _clip(spikeyness, 0, 1) * ave_radius
+    lower = (2 * math.pi / num_verts) - irregularity
+    upper = (2 * math.pi / num_verts) + irregularity
+    steps, total = [], 0
+    for _ in range(num_verts):
+        tmp = rng.uniform(lower, upper)
+        steps.append(tmp)
+        total = total + tmp
+    k = total / (2 * math.pi)
+    steps = [s / k for s in steps]
+    points = []
+    angle = rng.uniform(0, 2 * math.pi)
+    for i in range(num_verts):
+        r_i = _clip(rng.gauss(ave_radius, spikeyness), 0, 2 * ave_radius)
+        points.append((int(ctr_x + r_i * math.cos(angle)), int(ctr_y + r_i * math.sin(angle))))
+        angle = angle + steps[i]
+    return points
+
+
+def densify(points: Sequence[Point], target: float) -> List[Point]:
+    """Split every edge into equal pieces no longer than ``target`` (the edge densification the
+    drawing UI applies before saving, ui/tk-ui.py:252-276, restated as a pure function)."""
+    out: List[Point] = []
+    n = len(points)
+    for i in range(n):
+        x0, y0 = points[i]
+        x1, y1 = points[(i + 1) % n]
+        length = math.hypot(x1 - x0, y1 - y0)
+        pieces = max(1, int(math.ceil(length / target)))
+        for j in range(pieces):
+            t = j / pieces
+            out.append((x0 + (x1 - x0) * t, y0 + (y1 - y0) * t))
+    return out
+
+
+def random_domain(seed: int, num_verts: int | None = None, edge: float = 0.45) -> List[Point]:
+    """Config-5 style domain: a random star-shaped polygon in pixel coordinates, /100, made
+    clockwise (as ui/tk-ui.py:84-101,169-176 does on save) and densified to ``edge``."""
+    rng = random.Random(seed)
+    nv = num_verts if num_verts is not None else rng.randint(8, 64)
+    while True:
+        raw = generate_polygon(num_verts=nv, rng=rng)
+        pts = []
+        for p in raw:                      # drop consecutive duplicates from int() truncation
+            q = (p[0] / 100, p[1] / 100)
+            if not pts or q != pts[-1]:
+                pts.append(q)
+        if len(pts) > 1 and pts[0] == pts[-1]:
+            pts.pop()
+        if len(pts) >= 5:
+            break
+    if signed_area2(pts) > 0:
+        pts.reverse()
+    pts = densify(pts, edge)
+    # coordinates on the 1e-4 grid, like every vertex the environment itself creates
+    return [(round(x, 4), round(y, 4)) for x, y in pts]
+
+
+# --------------------------------------------------------------------------- constants
+
+def _distance(a: Point, b: Point) -> float:
+    # Point2D.distance_to, general/components.py:17-18 (`**` kept: it is libm pow, not a*a)
+    return math.sqrt((a[0] - b[0]) ** 2 + (a[1] - b[1]) ** 2)
+
+
+@dataclass(frozen=True)
+class DomainConstants:
+    n0: int
+    original_area: float
+    average_edge_length: float
+    est_min_l: float
+    est_crit_l: float
+
+
+def domain_constants(points: Sequence[Point]) -> DomainConstants:
+    n = len(points)
+    # Boundary2D.poly_area, general/components.py:477-479
+    xy = np.array([[x, y] for x, y in points])
+    area = 0.5 * np.abs(np.dot(xy[:, 0], np.roll(xy[:, 1], 1)) - np.dot(xy[:, 1], np.roll(xy[:, 0], 1)))
+    # Boundary2D.average_edge_length, general/components.py:442-447
+    dist = 0
+    for i in range(n):
+        dist += _distance(points[i], points[i - 1])
+    avg = round(dist / n, 4) if n != 0 else 0
+    # MeshGeneration.estimate_area_range, general/mesh.py:679-692, over the n ring edges
+    lengths = sorted(_distance(points[i - 1], points[i]) for i in range(n))
+    total = 0
+    for v in lengths:
+        total += v
+    L = total / len(lengths)
+    max_l = min(lengths[-2], 2 * L)
+    min_l = min(L / math.sqrt(2), lengths[1])
+    return DomainConstants(n0=n, original_area=float(area), average_edge_length=float(avg),
+                           est_min_l=float(min_l), est_crit_l=float((max_l + 3 * min_l) / 4))
