@@ -1,0 +1,187 @@
+/*
+ * meshenv.h -- C-ABI of libmeshenv_hip.so: the MI355X-native, vectorised replacement for the
+ * reference's BoudaryEnv step()/reset() hot path.
+ *
+ * The reference (ZhuoQiuMcgill/ReinforcementLearning4MeshGeneration) is pure Python and has no
+ * FFI layer; the boundary it exposes for this path is the Gym class surface
+ *   rl/boundary_env.py:18     class BoudaryEnv(MeshGeneration, gym.Env)
+ *   rl/boundary_env.py:67-84  reset()            -> meshenv_reset
+ *   rl/boundary_env.py:113-263 step(action)      -> meshenv_step
+ *   rl/baselines/dummy_vec_env.py:41-51 step_wait (the vectorised caller)  -> one meshenv_step per call
+ * so every entry point below cites the Python method it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MESHENV_E_* code on failure;
+ *     meshenv_last_error() returns a human-readable message for the last failure on that handle
+ *     (or for a failed meshenv_create when passed NULL);
+ *   - pointers named *_dev are DEVICE pointers (e.g. torch.Tensor.data_ptr() of a tensor on the
+ *     handle's GPU), owned by the caller, and must stay valid until the stream work that uses
+ *     them has completed; pointers named *_host are host pointers;
+ *   - a handle is bound to one GPU and one HIP stream; all work is stream-ordered on that stream;
+ *     handles are not thread-safe;
+ *   - there is no CPU fallback: every call fails with MESHENV_E_HIP if the GPU is unavailable.
+ */
+#ifndef MESHENV_H
+#define MESHENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MESHENV_ABI_VERSION 1
+
+#define MESHENV_OBS_DIM 18 /* observation_space shape, rl/boundary_env.py:38-39 */
+#define MESHENV_ACT_DIM 3  /* action_space shape, rl/boundary_env.py:27 */
+
+enum {
+    MESHENV_OK = 0,
+    MESHENV_E_ARG = -1,    /* bad argument (null pointer, size out of range, unsupported parameter) */
+    MESHENV_E_HIP = -2,    /* a HIP runtime call failed / no usable GPU */
+    MESHENV_E_RANGE = -3,  /* env / domain index out of range */
+    MESHENV_E_STATE = -4   /* call not valid in the handle's current state */
+};
+
+/* per-env status bits returned by meshenv_get_status() */
+enum {
+    MESHENV_ST_NO_REFERENCE = 1, /* candidate list empty: the reference's find_next_state() returned None
+                                    (rl/boundary_env.py:569-571); obs is all zeros */
+    MESHENV_ST_LOG_OVERFLOW = 2  /* more elements / new vertices than log_capacity; counts stay exact,
+                                    the log holds the first log_capacity entries */
+};
+
+/* Constants of rl/boundary_env.py:26-56, general/mesh.py:26-28 and general/components.py:721-722.
+ * meshenv_default_params() fills the reference's values.  neighbor_num and radius_num fix the
+ * observation layout and must stay 6 and 3. */
+typedef struct MeshEnvParams {
+    int32_t struct_size;        /* sizeof(MeshEnvParams), for ABI checking */
+    int32_t neighbor_num;       /* 6    rl/boundary_env.py:32 */
+    int32_t radius_num;         /* 3    rl/boundary_env.py:33 */
+    int32_t fail_limit;         /* 100  rl/boundary_env.py:260 */
+    int32_t log_capacity;       /* elements (and new vertices) logged per env per episode; 0 = no log */
+    int32_t reserved;
+    double radius;              /* 4      rl/boundary_env.py:35 */
+    double max_ref_angle;       /* 0.972*pi  general/mesh.py:26 */
+    double key_lambda;          /* 0.618  general/mesh.py:213 */
+    double min_degree;          /* 0.01*pi general/components.py:722 */
+    double max_degree;          /* 0.99*pi general/components.py:721 */
+    double same_point_eps;      /* 0.001  rl/boundary_env.py:601 */
+    double ray_length;          /* 10000  general/mesh.py:540 */
+} MeshEnvParams;
+
+typedef struct MeshEnv MeshEnv; /* opaque */
+
+void meshenv_default_params(MeshEnvParams *p);
+
+int meshenv_abi_version(void);
+
+/* Number of HIP devices visible (0 if none / runtime unusable). */
+int meshenv_device_count(void);
+
+/*
+ * Construct n_envs environments over n_domains polygons.
+ * Replaces BoudaryEnv.__init__ (rl/boundary_env.py:21-65) + MeshGeneration.__init__
+ * (general/mesh.py:17-30) for a whole batch.
+ *
+ *   dom_offsets_host[n_domains+1]  vertex offsets of each domain ring in dom_xy_host
+ *   dom_xy_host[2*total]           clockwise rings, (x, y) interleaved, float64
+ *   dom_consts_host[3*n_domains]   per domain: original_area, est_min_l, est_crit_l
+ *                                  (Boundary2D.poly_area, general/components.py:477-479;
+ *                                   MeshGeneration.estimate_area_range, general/mesh.py:679-692)
+ *   env_domain_host[n_envs]        domain index of every environment
+ *   stream                         hipStream_t to bind (NULL = the device's default stream)
+ *
+ * The environments come up already reset (their first observation is available through
+ * meshenv_reset with a NULL mask).
+ */
+int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, const double *dom_xy_host,
+                   const double *dom_consts_host, int n_envs, const int32_t *env_domain_host,
+                   const MeshEnvParams *params, void *stream, MeshEnv **out);
+
+void meshenv_destroy(MeshEnv *h);
+
+const char *meshenv_last_error(const MeshEnv *h);
+
+/* Rebind the handle to another HIP stream (e.g. torch.cuda.current_stream().cuda_stream). */
+int meshenv_set_stream(MeshEnv *h, void *stream);
+
+int meshenv_num_envs(const MeshEnv *h);
+int meshenv_max_ring(const MeshEnv *h);
+
+/*
+ * reset(): rl/boundary_env.py:67-84 for every env whose mask byte is non-zero (all envs when
+ * mask_dev is NULL).  obs_dev[n_envs*18] receives the first observation of the reset envs and the
+ * current observation of the others.
+ */
+int meshenv_reset(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev);
+
+/*
+ * step(): rl/boundary_env.py:113-263 for all envs, one kernel launch.
+ *   actions_dev[n_envs*3] float32   (rule type, x, y) as SB3 hands them over
+ *   obs_dev[n_envs*18]    float32   next observation (after auto-reset: the first observation of
+ *                                   the new episode, like SB3's DummyVecEnv)
+ *   reward_dev[n_envs]    float64   the reference returns np.float64 (rl/boundary_env.py:263)
+ *   done_dev[n_envs]      uint8
+ *   complete_dev[n_envs]  uint8     info['is_complete']
+ *   terminal_obs_dev      nullable; for envs with done != 0 receives the last observation of the
+ *                         finished episode (SB3's infos[k]["terminal_observation"])
+ *   auto_reset            non-zero: envs that finish are reset inside the same launch
+ */
+int meshenv_step(MeshEnv *h, const float *actions_dev, float *obs_dev, double *reward_dev, uint8_t *done_dev,
+                 uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset);
+
+/*
+ * n_steps consecutive step() calls in ONE launch (environments are independent, so a wave can
+ * advance its env without any inter-wave synchronisation).  actions_dev is [n_steps][n_envs][3];
+ * reward_dev/done_dev/complete_dev are [n_steps][n_envs]; obs_dev[n_envs*18] receives the
+ * observation after the last step; auto_reset as in meshenv_step.  Used for open-loop (scripted /
+ * random-policy) rollouts; a policy in the loop calls meshenv_step.
+ */
+int meshenv_rollout(MeshEnv *h, int n_steps, const float *actions_dev, float *obs_dev, double *reward_dev,
+                    uint8_t *done_dev, uint8_t *complete_dev, int auto_reset);
+
+/* Per-env status bits (MESHENV_ST_*) after the last step/reset; status_dev[n_envs]. */
+int meshenv_get_status(MeshEnv *h, uint8_t *status_dev);
+
+/*
+ * Host-side readout of one environment (synchronises the stream).  Any pointer may be NULL.
+ *   ring_ids_host[max_ring]      global vertex ids of updated_boundary.vertices, in ring order
+ *   ring_xy_host[2*max_ring]
+ *   cand_key_host[max_ring]      cached candidate key per ring slot (NaN where not a candidate)
+ *   cand_stamp_host[max_ring]    insertion stamp per ring slot (larger = nearer the list head
+ *                                among equal keys; INT32_MIN where not a candidate)
+ *   scalars_host[8]: ring length, reference ring index, n_elements (len(generated_meshes)),
+ *                    failed_num, n_vertices (len(boundary.vertices)), status bits, domain, n0
+ *   fscalars_host[2]: current_area, base_length
+ */
+int meshenv_get_state(MeshEnv *h, int env, int32_t *ring_ids_host, double *ring_xy_host, double *cand_key_host,
+                      int32_t *cand_stamp_host, int32_t *scalars_host, double *fscalars_host);
+
+/*
+ * generated_meshes / boundary.vertices of one env (rl/boundary_env.py:192, general/mesh.py:589-590):
+ *   quads_host[4*cap]      global vertex ids per element, in creation order
+ *   vertex_xy_host[2*cap]  coordinates of all vertices ever (initial ring first, then new ones)
+ * cap_elems / cap_verts are the capacities of the caller's buffers; *n_elem / *n_vert receive the
+ * number of entries written.
+ */
+int meshenv_get_elements(MeshEnv *h, int env, int32_t *quads_host, int cap_elems, double *vertex_xy_host,
+                         int cap_verts, int32_t *n_elem, int32_t *n_vert);
+
+/*
+ * Work counters since creation (roofline accounting), summed over envs:
+ *   out_host[0] env steps executed, [1] valid extractions, [2] sum of ring lengths over all steps,
+ *   [3] sum of ring lengths over valid steps.
+ */
+int meshenv_counters(MeshEnv *h, uint64_t *out_host);
+
+/* Duration in milliseconds of the most recent step/rollout kernel, measured with HIP events on the
+ * handle's stream (synchronises).  Enabled with meshenv_set_timing(h, 1). */
+int meshenv_set_timing(MeshEnv *h, int enable);
+int meshenv_last_kernel_ms(MeshEnv *h, float *ms_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MESHENV_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of libmeshenv_hip.so (include/meshenv.h).  Fails loudly when the library is missing:
+there is no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+OBS_DIM = 18
+ACT_DIM = 3
+
+ST_NO_REFERENCE = 1
+ST_LOG_OVERFLOW = 2
+
+
+class MeshEnvParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("neighbor_num", C.c_int32), ("radius_num", C.c_int32),
+        ("fail_limit", C.c_int32), ("log_capacity", C.c_int32), ("reserved", C.c_int32),
+        ("radius", C.c_double), ("max_ref_angle", C.c_double), ("key_lambda", C.c_double),
+        ("min_degree", C.c_double), ("max_degree", C.c_double), ("same_point_eps", C.c_double),
+        ("ray_length", C.c_double),
+    ]
+
+
+class MeshEnvError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/meshenv.h declares
+EXPORTS = [
+    "meshenv_default_params", "meshenv_abi_version", "meshenv_device_count", "meshenv_create", "meshenv_destroy",
+    "meshenv_last_error", "meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_reset",
+    "meshenv_step", "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",
+    "meshenv_counters", "meshenv_set_timing", "meshenv_last_kernel_ms",
+]
+
+
+def load():
+    """Load the HIP library (no GPU needed for loading; compute calls need one)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MeshEnvError(
+            f"{LIB_PATH} is missing: build it with `python -m reinforcementlearning4meshgeneration_amd.build` "
+            "(hipcc, gfx950).  This package has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, f64p, u8p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p, C.c_void_p
+    L.meshenv_default_params.argtypes = [C.POINTER(MeshEnvParams)]
+    L.meshenv_default_params.restype = None
+    L.meshenv_abi_version.restype = C.c_int
+    L.meshenv_device_count.restype = C.c_int
+    L.meshenv_create.argtypes = [C.c_int, C.c_int, i32p, f64p, f64p, C.c_int, i32p, C.POINTER(MeshEnvParams), vp,
+                                 C.POINTER(vp)]
+    L.meshenv_create.restype = C.c_int
+    L.meshenv_destroy.argtypes = [vp]
+    L.meshenv_destroy.restype = None
+    L.meshenv_last_error.argtypes = [vp]
+    L.meshenv_last_error.restype = C.c_char_p
+    L.meshenv_set_stream.argtypes = [vp, vp]
+    L.meshenv_num_envs.argtypes = [vp]
+    L.meshenv_max_ring.argtypes = [vp]
+    L.meshenv_reset.argtypes = [vp, u8p, f32p]
+    L.meshenv_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.meshenv_rollout.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
+    L.meshenv_get_status.argtypes = [vp, vp]
+    L.meshenv_get_state.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.meshenv_get_elements.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, i32p, i32p]
+    L.meshenv_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.meshenv_set_timing.argtypes = [vp, C.c_int]
+    L.meshenv_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    for name in ("meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_reset", "meshenv_step",
+                 "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",
+                 "meshenv_counters", "meshenv_set_timing", "meshenv_last_kernel_ms"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def default_params() -> MeshEnvParams:
+    p = MeshEnvParams()
+    load().meshenv_default_params(C.byref(p))
+    return p
+
+
+def check(handle, rc: int, what: str):
+    if rc != 0:
+        msg = load().meshenv_last_error(handle)
+        raise MeshEnvError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,50 @@
+"""Builds libmeshenv_hip.so (gfx950) in-tree with hipcc.  `python -m reinforcementlearning4meshgeneration_amd.build`."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_NAME = "libmeshenv_hip.so"
+LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
+SOURCES = ["meshenv_hip.hip"]
+HEADERS = ["meshenv_geom.h", "meshenv_state.h", "meshenv_kernels.h"]
+ARCH = "gfx950"
+
+# -ffp-contract=off: the reference is CPython float arithmetic, which never fuses a*b+c.
+# -fhip-fp32-correctly-rounded-divide-sqrt: numpy's float32 round() divides in IEEE float32.
+HIPCC_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+               "-fno-fast-math", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm to build libmeshenv_hip.so)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps.append(os.path.join(os.path.dirname(PKG_DIR), "include", "meshenv.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

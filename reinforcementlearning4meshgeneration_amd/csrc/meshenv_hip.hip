@@ -1,0 +1,465 @@
+// meshenv_hip.hip -- C-ABI (include/meshenv.h) over the wave-per-environment kernels.
+//
+// Host side: owns the HBM state of a batch of environments, launches k_init_domains / k_reset / k_step on
+// the handle's stream.  Nothing here computes environment results on the host: without a working GPU every
+// entry point fails with MESHENV_E_HIP.
+#include "../../include/meshenv.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "meshenv_kernels.h"
+
+using namespace meshenv;
+
+namespace {
+thread_local std::string g_create_error;
+}
+
+struct MeshEnv {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevState S{};
+    int n_envs = 0, n_domains = 0, cap = 0, max_ring = 0;
+    size_t lds = 0;
+    std::vector<int32_t> env_off_host, dom_off_host, env_dom_host;
+    std::vector<void *> allocs;
+    std::string err;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    uint8_t *status_tmp = nullptr;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                            \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                           \
+            return MESHENV_E_HIP;                                                                   \
+        }                                                                                           \
+    } while (0)
+
+template <typename T>
+int dev_alloc(MeshEnv *h, T **out, size_t count)
+{
+    void *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(&p, count * sizeof(T));
+    if (e != hipSuccess) {
+        h->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return MESHENV_E_HIP;
+    }
+    h->allocs.push_back(p);
+    *out = (T *)p;
+    return MESHENV_OK;
+}
+
+int fail_arg(MeshEnv *h, const char *msg)
+{
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return MESHENV_E_ARG;
+}
+
+}  // namespace
+
+extern "C" {
+
+void meshenv_default_params(MeshEnvParams *p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->struct_size = (int32_t)sizeof(MeshEnvParams);
+    p->neighbor_num = 6;
+    p->radius_num = 3;
+    p->fail_limit = 100;
+    p->log_capacity = 0;
+    p->radius = 4;
+    p->max_ref_angle = kPi * 0.972;
+    p->key_lambda = 0.618;
+    p->min_degree = 0.01 * kPi;
+    p->max_degree = 0.99 * kPi;
+    p->same_point_eps = 0.001;
+    p->ray_length = 10000;
+}
+
+int meshenv_abi_version(void) { return MESHENV_ABI_VERSION; }
+
+int meshenv_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *meshenv_last_error(const MeshEnv *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void meshenv_destroy(MeshEnv *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, const double *dom_xy_host,
+                   const double *dom_consts_host, int n_envs, const int32_t *env_domain_host,
+                   const MeshEnvParams *params, void *stream, MeshEnv **out)
+{
+    if (!out) return fail_arg(nullptr, "meshenv_create: out is NULL");
+    *out = nullptr;
+    if (n_domains <= 0 || n_envs <= 0 || !dom_offsets_host || !dom_xy_host || !dom_consts_host || !env_domain_host)
+        return fail_arg(nullptr, "meshenv_create: null or empty input");
+    MeshEnvParams prm;
+    meshenv_default_params(&prm);
+    if (params) {
+        if (params->struct_size != (int32_t)sizeof(MeshEnvParams))
+            return fail_arg(nullptr, "meshenv_create: MeshEnvParams.struct_size mismatch (ABI)");
+        prm = *params;
+    }
+    if (prm.neighbor_num != 6 || prm.radius_num != 3)
+        return fail_arg(nullptr, "meshenv_create: neighbor_num must be 6 and radius_num 3 (observation layout)");
+    if (prm.fail_limit <= 0 || prm.log_capacity < 0 || !(prm.radius > 0))
+        return fail_arg(nullptr, "meshenv_create: bad parameter value");
+
+    int max_ring = 0;
+    for (int d = 0; d < n_domains; d++) {
+        const int n0 = dom_offsets_host[d + 1] - dom_offsets_host[d];
+        if (n0 < 4) return fail_arg(nullptr, "meshenv_create: a domain ring needs at least 4 vertices");
+        max_ring = n0 > max_ring ? n0 : max_ring;
+    }
+    for (int e = 0; e < n_envs; e++)
+        if (env_domain_host[e] < 0 || env_domain_host[e] >= n_domains)
+            return fail_arg(nullptr, "meshenv_create: env_domain entry out of range");
+    const int cap = (max_ring + 15) / 16 * 16;
+    const size_t lds = lds_bytes_for(cap);
+    if (lds > 160 * 1024) return fail_arg(nullptr, "meshenv_create: ring too long for one CU's LDS (max ~4800 vertices)");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = "meshenv_create: no HIP device available (this library has no CPU fallback)";
+        return MESHENV_E_HIP;
+    }
+    if (device < 0 || device >= ndev) return fail_arg(nullptr, "meshenv_create: device index out of range");
+
+    MeshEnv *h = new MeshEnv();
+    h->device = device;
+    h->stream = (hipStream_t)stream;
+    h->n_envs = n_envs;
+    h->n_domains = n_domains;
+    h->cap = cap;
+    h->max_ring = max_ring;
+    h->lds = lds;
+#define CREATE_TRY(expr)                                            \
+    do {                                                            \
+        int _rc = (expr);                                           \
+        if (_rc != MESHENV_OK) {                                    \
+            g_create_error = h->err;                                \
+            meshenv_destroy(h);                                     \
+            return _rc;                                             \
+        }                                                           \
+    } while (0)
+#define CREATE_HIP(expr)                                                                \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            g_create_error = std::string(#expr) + ": " + hipGetErrorString(_e);         \
+            meshenv_destroy(h);                                                         \
+            return MESHENV_E_HIP;                                                       \
+        }                                                                               \
+    } while (0)
+
+    CREATE_HIP(hipSetDevice(device));
+    if (lds > 64 * 1024) {
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_init_domains, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+
+    DevState &S = h->S;
+    S.n_domains = n_domains;
+    S.n_envs = n_envs;
+    S.prm.radius = prm.radius;
+    S.prm.max_ref_angle = prm.max_ref_angle;
+    S.prm.w0 = prm.key_lambda;
+    S.prm.w1 = 1 - prm.key_lambda;
+    S.prm.min_degree = prm.min_degree;
+    S.prm.max_degree = prm.max_degree;
+    S.prm.same_eps = prm.same_point_eps;
+    S.prm.ray_length = prm.ray_length;
+    S.prm.fail_limit = prm.fail_limit;
+    S.prm.log_cap = prm.log_capacity;
+
+    const int total_dom = dom_offsets_host[n_domains];
+    h->dom_off_host.assign(dom_offsets_host, dom_offsets_host + n_domains + 1);
+    h->env_dom_host.assign(env_domain_host, env_domain_host + n_envs);
+    h->env_off_host.resize((size_t)n_envs + 1);
+    h->env_off_host[0] = 0;
+    for (int e = 0; e < n_envs; e++) {
+        const int d = env_domain_host[e];
+        const long long next = (long long)h->env_off_host[e] + (dom_offsets_host[d + 1] - dom_offsets_host[d]);
+        if (next > 0x7fffffffLL) {
+            g_create_error = "meshenv_create: total ring storage exceeds 2^31 vertices";
+            meshenv_destroy(h);
+            return MESHENV_E_ARG;
+        }
+        h->env_off_host[e + 1] = (int32_t)next;
+    }
+    const size_t total_env = (size_t)h->env_off_host[n_envs];
+
+    int32_t *d_dom_off = nullptr, *d_env_off = nullptr;
+    double2 *d_dom_xy = nullptr;
+    DomConst *d_dom_const = nullptr;
+    CREATE_TRY(dev_alloc(h, &d_dom_off, (size_t)n_domains + 1));
+    CREATE_TRY(dev_alloc(h, &d_dom_xy, (size_t)total_dom));
+    CREATE_TRY(dev_alloc(h, &S.dom_key, (size_t)total_dom));
+    CREATE_TRY(dev_alloc(h, &S.dom_stamp, (size_t)total_dom));
+    CREATE_TRY(dev_alloc(h, &d_dom_const, (size_t)n_domains));
+    CREATE_TRY(dev_alloc(h, &S.dom_obs, (size_t)n_domains * kObsDim));
+    CREATE_TRY(dev_alloc(h, &S.dom_ref, (size_t)n_domains));
+    CREATE_TRY(dev_alloc(h, &S.dom_bl, (size_t)n_domains));
+    CREATE_TRY(dev_alloc(h, &d_env_off, (size_t)n_envs + 1));
+    CREATE_TRY(dev_alloc(h, &S.ring_xy, total_env));
+    CREATE_TRY(dev_alloc(h, &S.ring_id, total_env));
+    CREATE_TRY(dev_alloc(h, &S.ring_key, total_env));
+    CREATE_TRY(dev_alloc(h, &S.ring_stamp, total_env));
+    CREATE_TRY(dev_alloc(h, &S.scal, (size_t)n_envs));
+    CREATE_TRY(dev_alloc(h, &S.cnt, (size_t)n_envs));
+    CREATE_TRY(dev_alloc(h, &S.obs_cache, (size_t)n_envs * kObsDim));
+    CREATE_TRY(dev_alloc(h, &h->status_tmp, (size_t)n_envs));
+    if (prm.log_capacity > 0) {
+        CREATE_TRY(dev_alloc(h, &S.log_quads, (size_t)n_envs * prm.log_capacity * 4));
+        CREATE_TRY(dev_alloc(h, &S.log_vxy, (size_t)n_envs * prm.log_capacity));
+    }
+    S.dom_off = d_dom_off;
+    S.dom_xy = d_dom_xy;
+    S.dom_const = d_dom_const;
+    S.env_off = d_env_off;
+
+    std::vector<DomConst> dc((size_t)n_domains);
+    for (int d = 0; d < n_domains; d++) {
+        dc[d].orig_area = dom_consts_host[3 * d];
+        dc[d].min_area = dom_consts_host[3 * d + 1] * dom_consts_host[3 * d + 1];   // estimated_area_range[0] ** 2
+        dc[d].crit_area = dom_consts_host[3 * d + 2] * dom_consts_host[3 * d + 2];  // estimated_area_range[1] ** 2
+        dc[d].pad = 0;
+    }
+    std::vector<EnvScalars> sc((size_t)n_envs);
+    std::memset(sc.data(), 0, sc.size() * sizeof(EnvScalars));
+    for (int e = 0; e < n_envs; e++) sc[e].dom = env_domain_host[e];
+
+    CREATE_HIP(hipMemcpy(d_dom_off, dom_offsets_host, sizeof(int32_t) * ((size_t)n_domains + 1), hipMemcpyHostToDevice));
+    CREATE_HIP(hipMemcpy(d_dom_xy, dom_xy_host, sizeof(double2) * (size_t)total_dom, hipMemcpyHostToDevice));
+    CREATE_HIP(hipMemcpy(d_dom_const, dc.data(), sizeof(DomConst) * (size_t)n_domains, hipMemcpyHostToDevice));
+    CREATE_HIP(hipMemcpy(d_env_off, h->env_off_host.data(), sizeof(int32_t) * ((size_t)n_envs + 1), hipMemcpyHostToDevice));
+    CREATE_HIP(hipMemcpy(S.scal, sc.data(), sizeof(EnvScalars) * (size_t)n_envs, hipMemcpyHostToDevice));
+    CREATE_HIP(hipEventCreate(&h->ev0));
+    CREATE_HIP(hipEventCreate(&h->ev1));
+
+    hipLaunchKernelGGL(k_init_domains, dim3(n_domains), dim3(64), lds, h->stream, S, cap);
+    CREATE_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_reset, dim3(n_envs), dim3(64), lds, h->stream, S, cap, (const uint8_t *)nullptr, (float *)nullptr, 1);
+    CREATE_HIP(hipGetLastError());
+    CREATE_HIP(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+#undef CREATE_HIP
+    *out = h;
+    return MESHENV_OK;
+}
+
+int meshenv_set_stream(MeshEnv *h, void *stream)
+{
+    if (!h) return MESHENV_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->stream = (hipStream_t)stream;
+    return MESHENV_OK;
+}
+
+int meshenv_num_envs(const MeshEnv *h) { return h ? h->n_envs : MESHENV_E_ARG; }
+int meshenv_max_ring(const MeshEnv *h) { return h ? h->max_ring : MESHENV_E_ARG; }
+
+int meshenv_reset(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev)
+{
+    if (!h) return MESHENV_E_ARG;
+    hipLaunchKernelGGL(k_reset, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, mask_dev, obs_dev, 0);
+    HIP_TRY(h, hipGetLastError());
+    return MESHENV_OK;
+}
+
+static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float *obs_dev, double *reward_dev,
+                       uint8_t *done_dev, uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset)
+{
+    if (!h) return MESHENV_E_ARG;
+    if (!actions_dev || !obs_dev || !reward_dev || !done_dev || !complete_dev) return fail_arg(h, "meshenv_step: null device pointer");
+    if (n_steps <= 0) return fail_arg(h, "meshenv_rollout: n_steps must be positive");
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(k_step, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, n_steps, actions_dev, obs_dev,
+                       reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) {
+        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+        h->ev_valid = true;
+    }
+    return MESHENV_OK;
+}
+
+int meshenv_step(MeshEnv *h, const float *actions_dev, float *obs_dev, double *reward_dev, uint8_t *done_dev,
+                 uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset)
+{
+    return launch_step(h, 1, actions_dev, obs_dev, reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
+}
+
+int meshenv_rollout(MeshEnv *h, int n_steps, const float *actions_dev, float *obs_dev, double *reward_dev,
+                    uint8_t *done_dev, uint8_t *complete_dev, int auto_reset)
+{
+    return launch_step(h, n_steps, actions_dev, obs_dev, reward_dev, done_dev, complete_dev, nullptr, auto_reset);
+}
+
+__global__ void k_status(DevState S, uint8_t *out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < S.n_envs) out[e] = (uint8_t)S.scal[e].status;
+}
+
+int meshenv_get_status(MeshEnv *h, uint8_t *status_dev)
+{
+    if (!h || !status_dev) return MESHENV_E_ARG;
+    hipLaunchKernelGGL(k_status, dim3((h->n_envs + 255) / 256), dim3(256), 0, h->stream, h->S, status_dev);
+    HIP_TRY(h, hipGetLastError());
+    return MESHENV_OK;
+}
+
+int meshenv_get_state(MeshEnv *h, int env, int32_t *ring_ids_host, double *ring_xy_host, double *cand_key_host,
+                      int32_t *cand_stamp_host, int32_t *scalars_host, double *fscalars_host)
+{
+    if (!h) return MESHENV_E_ARG;
+    if (env < 0 || env >= h->n_envs) {
+        h->err = "meshenv_get_state: env out of range";
+        return MESHENV_E_RANGE;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    EnvScalars s;
+    HIP_TRY(h, hipMemcpy(&s, h->S.scal + env, sizeof(s), hipMemcpyDeviceToHost));
+    const size_t off = (size_t)h->env_off_host[env];
+    const int n0 = h->env_off_host[env + 1] - h->env_off_host[env];
+    const int n = s.n;
+    if (ring_ids_host) HIP_TRY(h, hipMemcpy(ring_ids_host, h->S.ring_id + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (ring_xy_host) HIP_TRY(h, hipMemcpy(ring_xy_host, h->S.ring_xy + off, sizeof(double2) * n, hipMemcpyDeviceToHost));
+    if (cand_stamp_host || cand_key_host) {
+        std::vector<int32_t> st((size_t)n);
+        std::vector<double> ky((size_t)n);
+        HIP_TRY(h, hipMemcpy(st.data(), h->S.ring_stamp + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(ky.data(), h->S.ring_key + off, sizeof(double) * n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) {
+            if (cand_stamp_host) cand_stamp_host[i] = st[i];
+            if (cand_key_host) cand_key_host[i] = st[i] == kNotCand ? NAN : ky[i];
+        }
+    }
+    if (scalars_host) {
+        scalars_host[0] = s.n;
+        scalars_host[1] = s.ref;
+        scalars_host[2] = s.n_elem;
+        scalars_host[3] = s.failed;
+        scalars_host[4] = n0 + s.n_new;
+        scalars_host[5] = s.status;
+        scalars_host[6] = s.dom;
+        scalars_host[7] = n0;
+    }
+    if (fscalars_host) {
+        fscalars_host[0] = s.area;
+        fscalars_host[1] = s.bl;
+    }
+    return MESHENV_OK;
+}
+
+int meshenv_get_elements(MeshEnv *h, int env, int32_t *quads_host, int cap_elems, double *vertex_xy_host,
+                         int cap_verts, int32_t *n_elem, int32_t *n_vert)
+{
+    if (!h || !n_elem || !n_vert) return MESHENV_E_ARG;
+    if (env < 0 || env >= h->n_envs) {
+        h->err = "meshenv_get_elements: env out of range";
+        return MESHENV_E_RANGE;
+    }
+    const int cap = h->S.prm.log_cap;
+    if (cap <= 0) {
+        h->err = "meshenv_get_elements: handle was created with log_capacity = 0";
+        return MESHENV_E_STATE;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    EnvScalars s;
+    HIP_TRY(h, hipMemcpy(&s, h->S.scal + env, sizeof(s), hipMemcpyDeviceToHost));
+    const int d = s.dom;
+    const int n0 = h->dom_off_host[d + 1] - h->dom_off_host[d];
+    int ne = s.n_elem < cap ? s.n_elem : cap;
+    int nnew = s.n_new < cap ? s.n_new : cap;
+    if (ne > cap_elems) ne = cap_elems;
+    int nv = n0 + nnew;
+    if (nv > cap_verts) nv = cap_verts;
+    if (quads_host && ne > 0)
+        HIP_TRY(h, hipMemcpy(quads_host, h->S.log_quads + (size_t)env * cap * 4, sizeof(int32_t) * 4 * (size_t)ne, hipMemcpyDeviceToHost));
+    if (vertex_xy_host && nv > 0) {
+        const int first = nv < n0 ? nv : n0;
+        HIP_TRY(h, hipMemcpy(vertex_xy_host, h->S.dom_xy + h->dom_off_host[d], sizeof(double2) * (size_t)first, hipMemcpyDeviceToHost));
+        if (nv > n0)
+            HIP_TRY(h, hipMemcpy(vertex_xy_host + 2 * (size_t)n0, h->S.log_vxy + (size_t)env * cap, sizeof(double2) * (size_t)(nv - n0), hipMemcpyDeviceToHost));
+    }
+    *n_elem = ne;
+    *n_vert = nv;
+    return MESHENV_OK;
+}
+
+int meshenv_counters(MeshEnv *h, uint64_t *out_host)
+{
+    if (!h || !out_host) return MESHENV_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<EnvCounters> c((size_t)h->n_envs);
+    HIP_TRY(h, hipMemcpy(c.data(), h->S.cnt, sizeof(EnvCounters) * (size_t)h->n_envs, hipMemcpyDeviceToHost));
+    uint64_t a = 0, b = 0, s = 0, sv = 0;
+    for (const EnvCounters &k : c) {
+        a += k.steps;
+        b += k.valid;
+        s += k.sum_n;
+        sv += k.sum_n_valid;
+    }
+    out_host[0] = a;
+    out_host[1] = b;
+    out_host[2] = s;
+    out_host[3] = sv;
+    return MESHENV_OK;
+}
+
+int meshenv_set_timing(MeshEnv *h, int enable)
+{
+    if (!h) return MESHENV_E_ARG;
+    h->timing = enable != 0;
+    h->ev_valid = false;
+    return MESHENV_OK;
+}
+
+int meshenv_last_kernel_ms(MeshEnv *h, float *ms_host)
+{
+    if (!h || !ms_host) return MESHENV_E_ARG;
+    if (!h->ev_valid) {
+        h->err = "meshenv_last_kernel_ms: timing not enabled or no step launched yet";
+        return MESHENV_E_STATE;
+    }
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    HIP_TRY(h, hipEventElapsedTime(ms_host, h->ev0, h->ev1));
+    return MESHENV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,333 @@
+"""Vectorised BoudaryEnv on MI355X: thousands of independent boundary polygons advanced by one HIP kernel
+launch per step (libmeshenv_hip.so), observations/actions/rewards as PyTorch-ROCm tensors.
+
+Two call surfaces over the same engine:
+
+* tensor-native -- ``reset() / step(actions) / rollout(actions)`` take and return CUDA tensors; nothing
+  crosses PCIe.  This is what an on-device policy (SAC actor MLP) talks to.
+* SB3 ``VecEnv``-shaped -- ``step_async / step_wait / reset / get_attr / env_method ...`` with numpy arrays,
+  auto-reset, ``infos[k]["terminal_observation"]`` and ``infos[k]["TimeLimit.truncated"]``, i.e. the contract
+  of the reference's vectorised caller (rl/baselines/dummy_vec_env.py:12-125) so Stable-Baselines3 plugs in
+  unchanged.
+
+The Gym surface constants come from rl/boundary_env.py:27 (action Box) and :38-39 (observation Box).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+from .domains import Point, domain_constants
+
+ACTION_LOW = np.array([-1.0, -1.5, 0.0], dtype=np.float32)   # rl/boundary_env.py:27
+ACTION_HIGH = np.array([1.0, 1.5, 1.5], dtype=np.float32)
+OBS_LOW, OBS_HIGH = -999.0, 999.0                            # rl/boundary_env.py:38-39
+OBS_DIM = _capi.OBS_DIM
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box, used only when neither gymnasium nor gym is importable."""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        if shape is not None:
+            self.low = np.full(tuple(shape), low, dtype=dtype)
+            self.high = np.full(tuple(shape), high, dtype=dtype)
+        else:
+            self.low = np.asarray(low, dtype=dtype)
+            self.high = np.asarray(high, dtype=dtype)
+        self.shape = self.low.shape
+        self.dtype = np.dtype(dtype)
+        self._rng = np.random.default_rng()
+
+    def seed(self, seed=None):
+        self._rng = np.random.default_rng(seed)
+
+    def sample(self):
+        return self._rng.uniform(self.low, self.high).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    def __repr__(self):
+        return f"Box({self.low}, {self.high}, {self.shape}, {self.dtype})"
+
+
+def make_spaces():
+    """(observation_space, action_space) with the reference's bounds; real gymnasium/gym Boxes if available."""
+    box = None
+    for mod in ("gymnasium", "gym"):
+        try:
+            box = __import__(mod).spaces.Box
+            break
+        except Exception:
+            continue
+    if box is None:
+        return Box(OBS_LOW, OBS_HIGH, shape=(OBS_DIM,), dtype=np.float32), Box(ACTION_LOW, ACTION_HIGH, dtype=np.float32)
+    return (box(low=OBS_LOW, high=OBS_HIGH, shape=(OBS_DIM,), dtype=np.float32),
+            box(low=ACTION_LOW, high=ACTION_HIGH, dtype=np.float32))
+
+
+class MeshVecEnv:
+    """n_envs boundary environments on one GPU.
+
+    domains      list of polygons (each a clockwise list of (x, y)); see ``domains.py``
+    env_domain   domain index per env (default: env k uses domain k % len(domains))
+    device       CUDA/HIP device index
+    log_capacity elements / new vertices logged per env per episode (needed for ``generated_meshes``)
+    """
+
+    def __init__(self, domains: Sequence[Sequence[Point]], n_envs: Optional[int] = None,
+                 env_domain: Optional[Sequence[int]] = None, device: int = 0, log_capacity: int = 0,
+                 auto_reset: bool = True, fail_limit: int = 100, lazy_infos: bool = True):
+        import torch
+
+        self._torch = torch
+        self._L = _capi.load()
+        if not torch.cuda.is_available():
+            raise _capi.MeshEnvError("MeshVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                     "this package has no CPU fallback")
+        if len(domains) == 0:
+            raise ValueError("at least one domain is required")
+        if env_domain is None:
+            n_envs = len(domains) if n_envs is None else int(n_envs)
+            env_domain = np.arange(n_envs, dtype=np.int32) % len(domains)
+        env_domain = np.ascontiguousarray(env_domain, dtype=np.int32)
+        self.num_envs = int(len(env_domain))
+        self.device = torch.device("cuda", device)
+        self.auto_reset = bool(auto_reset)
+        self.lazy_infos = bool(lazy_infos)
+        self.log_capacity = int(log_capacity)
+        self.domains = [list(d) for d in domains]
+        self.constants = [domain_constants(d) for d in self.domains]
+        self.env_domain = env_domain
+
+        offs = np.zeros(len(domains) + 1, dtype=np.int32)
+        for k, d in enumerate(self.domains):
+            offs[k + 1] = offs[k] + len(d)
+        xy = np.ascontiguousarray(np.concatenate([np.asarray(d, dtype=np.float64).reshape(-1, 2) for d in self.domains]))
+        consts = np.ascontiguousarray(
+            np.array([[c.original_area, c.est_min_l, c.est_crit_l] for c in self.constants], dtype=np.float64))
+        prm = _capi.default_params()
+        prm.log_capacity = self.log_capacity
+        prm.fail_limit = int(fail_limit)
+        self._handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self._L.meshenv_create(
+                device, len(self.domains), offs.ctypes.data_as(C.POINTER(C.c_int32)),
+                xy.ctypes.data_as(C.POINTER(C.c_double)), consts.ctypes.data_as(C.POINTER(C.c_double)),
+                self.num_envs, env_domain.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(prm), C.c_void_p(stream),
+                C.byref(self._handle))
+        if rc != 0:
+            msg = self._L.meshenv_last_error(None)
+            raise _capi.MeshEnvError(f"meshenv_create failed (code {rc}): {msg.decode() if msg else ''}")
+        self.max_ring = self._L.meshenv_max_ring(self._handle)
+        n = self.num_envs
+        self.obs = torch.zeros((n, OBS_DIM), dtype=torch.float32, device=self.device)
+        self.terminal_obs = torch.zeros((n, OBS_DIM), dtype=torch.float32, device=self.device)
+        self.reward = torch.zeros(n, dtype=torch.float64, device=self.device)
+        self.done = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self.complete = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self._status = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self.observation_space, self.action_space = make_spaces()
+        self._pending_actions = None
+        self._closed = False
+        self.reset()
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc, what):
+        _capi.check(self._handle, rc, what)
+
+    def _bind_stream(self):
+        stream = self._torch.cuda.current_stream(self.device).cuda_stream
+        if stream != getattr(self, "_stream", None):
+            self._check(self._L.meshenv_set_stream(self._handle, C.c_void_p(stream)), "meshenv_set_stream")
+            self._stream = stream
+
+    def close(self):
+        if not self._closed and self._handle:
+            self._L.meshenv_destroy(self._handle)
+            self._handle = C.c_void_p()
+            self._closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ tensor-native API
+    def reset(self, mask=None):
+        """reset() of rl/boundary_env.py:67-84 for all envs (or those with mask != 0).  Returns obs [n,18]."""
+        self._bind_stream()
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=self._torch.uint8).contiguous()
+            mptr = C.c_void_p(mask.data_ptr())
+        self._check(self._L.meshenv_reset(self._handle, mptr, C.c_void_p(self.obs.data_ptr())), "meshenv_reset")
+        return self.obs
+
+    def step(self, actions):
+        """One step() of every env.  actions: float32 CUDA tensor [n, 3].
+        Returns (obs, reward, done, complete) -- views of buffers that the next call overwrites."""
+        t = self._torch
+        if actions.dtype != t.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=t.float32).contiguous()
+        if actions.shape != (self.num_envs, 3):
+            raise ValueError(f"actions must have shape ({self.num_envs}, 3), got {tuple(actions.shape)}")
+        self._bind_stream()
+        rc = self._L.meshenv_step(self._handle, actions.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
+                                  self.done.data_ptr(), self.complete.data_ptr(), self.terminal_obs.data_ptr(),
+                                  1 if self.auto_reset else 0)
+        self._check(rc, "meshenv_step")
+        return self.obs, self.reward, self.done, self.complete
+
+    def rollout(self, actions):
+        """T consecutive steps in one kernel launch.  actions: float32 CUDA tensor [T, n, 3].
+        Returns (obs_after_last_step [n,18], reward [T,n], done [T,n], complete [T,n])."""
+        t = self._torch
+        if actions.dtype != t.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=t.float32).contiguous()
+        if actions.dim() != 3 or actions.shape[1:] != (self.num_envs, 3):
+            raise ValueError(f"actions must have shape (T, {self.num_envs}, 3), got {tuple(actions.shape)}")
+        T = int(actions.shape[0])
+        reward = t.empty((T, self.num_envs), dtype=t.float64, device=self.device)
+        done = t.empty((T, self.num_envs), dtype=t.uint8, device=self.device)
+        complete = t.empty((T, self.num_envs), dtype=t.uint8, device=self.device)
+        self._bind_stream()
+        rc = self._L.meshenv_rollout(self._handle, T, actions.data_ptr(), self.obs.data_ptr(), reward.data_ptr(),
+                                     done.data_ptr(), complete.data_ptr(), 1 if self.auto_reset else 0)
+        self._check(rc, "meshenv_rollout")
+        return self.obs, reward, done, complete
+
+    def status(self):
+        self._bind_stream()
+        self._check(self._L.meshenv_get_status(self._handle, self._status.data_ptr()), "meshenv_get_status")
+        return self._status
+
+    # ------------------------------------------------------------------ introspection (host side)
+    def get_state(self, env: int) -> dict:
+        m = self.max_ring
+        ids = np.zeros(m, np.int32)
+        xy = np.zeros(2 * m, np.float64)
+        key = np.zeros(m, np.float64)
+        stamp = np.zeros(m, np.int32)
+        sc = np.zeros(8, np.int32)
+        fs = np.zeros(2, np.float64)
+        rc = self._L.meshenv_get_state(self._handle, int(env), ids.ctypes.data, xy.ctypes.data, key.ctypes.data,
+                                       stamp.ctypes.data, sc.ctypes.data, fs.ctypes.data)
+        self._check(rc, "meshenv_get_state")
+        n = int(sc[0])
+        ids, xy, key, stamp = ids[:n], xy[:2 * n].reshape(-1, 2), key[:n], stamp[:n]
+        cand = np.nonzero(stamp != np.iinfo(np.int32).min)[0]
+        order = sorted(cand.tolist(), key=lambda i: (key[i], -int(stamp[i])))
+        return dict(n=n, ring_ids=ids, ring_xy=xy, cand_key=key, cand_stamp=stamp,
+                    cand_order_ids=ids[order] if order else np.zeros(0, np.int32), cand_order_keys=key[order],
+                    ref_index=int(sc[1]), ref_id=int(ids[sc[1]]) if sc[1] >= 0 else -1, n_elem=int(sc[2]),
+                    failed_num=int(sc[3]), n_vert=int(sc[4]), status=int(sc[5]), domain=int(sc[6]), n0=int(sc[7]),
+                    current_area=float(fs[0]), base_length=float(fs[1]))
+
+    def get_elements(self, env: int):
+        """(quads [n_elem,4] global vertex ids, vertex_xy [n_vert,2]) of the env's current episode."""
+        if self.log_capacity <= 0:
+            raise _capi.MeshEnvError("create the MeshVecEnv with log_capacity > 0 to read generated meshes")
+        cap_e = self.log_capacity
+        cap_v = self.max_ring + self.log_capacity
+        quads = np.zeros(4 * cap_e, np.int32)
+        vxy = np.zeros(2 * cap_v, np.float64)
+        ne, nv = C.c_int32(0), C.c_int32(0)
+        rc = self._L.meshenv_get_elements(self._handle, int(env), quads.ctypes.data, cap_e, vxy.ctypes.data, cap_v,
+                                          C.byref(ne), C.byref(nv))
+        self._check(rc, "meshenv_get_elements")
+        return quads[:4 * ne.value].reshape(-1, 4).copy(), vxy[:2 * nv.value].reshape(-1, 2).copy()
+
+    def counters(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        self._check(self._L.meshenv_counters(self._handle, out), "meshenv_counters")
+        return dict(steps=int(out[0]), valid=int(out[1]), sum_ring=int(out[2]), sum_ring_valid=int(out[3]))
+
+    def set_timing(self, enable: bool):
+        self._check(self._L.meshenv_set_timing(self._handle, 1 if enable else 0), "meshenv_set_timing")
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0)
+        self._check(self._L.meshenv_last_kernel_ms(self._handle, C.byref(ms)), "meshenv_last_kernel_ms")
+        return float(ms.value)
+
+    # ------------------------------------------------------------------ SB3 VecEnv-shaped API (numpy)
+    def step_async(self, actions):
+        self._pending_actions = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, 3)
+
+    def step_wait(self):
+        t = self._torch
+        if self._pending_actions is None:
+            raise RuntimeError("step_wait() without step_async()")
+        act = t.from_numpy(self._pending_actions).to(self.device, non_blocking=False)
+        self._pending_actions = None
+        obs, rew, done, comp = self.step(act)
+        obs_np = obs.cpu().numpy()
+        rew_np = rew.cpu().numpy().astype(np.float32)
+        done_np = done.cpu().numpy().astype(bool)
+        comp_np = comp.cpu().numpy().astype(bool)
+        infos = self._build_infos(done_np, comp_np)
+        return obs_np, rew_np, done_np, infos
+
+    def step_numpy(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def _build_infos(self, done_np, comp_np) -> List[dict]:
+        if self.lazy_infos:
+            shared = {"is_complete": True}
+            infos = [shared] * self.num_envs
+        else:
+            infos = [{"is_complete": bool(c)} for c in comp_np]
+        idx = np.nonzero(done_np)[0]
+        if idx.size:
+            infos = list(infos)
+            term = self.terminal_obs.cpu().numpy()
+            for k in idx:
+                infos[k] = {"is_complete": bool(comp_np[k]), "terminal_observation": term[k].copy(),
+                            "TimeLimit.truncated": not bool(comp_np[k])}
+        return infos
+
+    def reset_numpy(self):
+        return self.reset().cpu().numpy()
+
+    def seed(self, seed=None):
+        # step()/reset() of the reference contain no RNG; only the action space sampler is seeded
+        if hasattr(self.action_space, "seed"):
+            self.action_space.seed(seed)
+        return [seed] * self.num_envs
+
+    def get_attr(self, attr_name, indices=None):
+        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+        return [self._env_attr(attr_name, i) for i in idx]
+
+    def _env_attr(self, name, i):
+        if name == "generated_meshes":
+            quads, vxy = self.get_elements(i)
+            return [vxy[q] for q in quads]
+        st = self.get_state(i)
+        if name in st:
+            return st[name]
+        if name in ("observation_space", "action_space"):
+            return getattr(self, name)
+        raise AttributeError(name)
+
+    def set_attr(self, attr_name, value, indices=None):
+        raise AttributeError(f"MeshVecEnv has no settable per-env attribute {attr_name!r}")
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        raise AttributeError(f"MeshVecEnv has no per-env method {method_name!r}")
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+        return [False for _ in idx]
+
+    def render(self, mode="human"):
+        return None

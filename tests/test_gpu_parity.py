@@ -1,0 +1,183 @@
+"""GPU: the HIP path (through the C-ABI, via MeshVecEnv) against
+  (a) the golden traces recorded from the reference itself, and
+  (b) the CPU oracle on seeded random action streams (BASELINE.json configs[1]: 4096 x boundary()).
+
+Bars: ring topology / counters / flags bit-exact; observations and rewards within 1e-5 of the oracle
+(BASELINE.json north_star).  Observations are additionally required to be bit-identical in all but a
+vanishing fraction of entries: the only arithmetic differences between device and oracle are the 1-ulp
+libm-vs-ocml transcendental results and pow(x,2)-vs-x*x, see DESIGN.md.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, golden_names
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device")
+    return torch
+
+
+def _mk(domains, **kw):
+    from reinforcementlearning4meshgeneration_amd.vec_env import MeshVecEnv
+    return MeshVecEnv(domains, **kw)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_hip_matches_reference_trace(torch_cuda, name):
+    torch = torch_cuda
+    tr = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    pts = [tuple(p) for p in tr["domain_xy"]]
+    env = _mk([pts], n_envs=1, auto_reset=False, log_capacity=512)
+    # the fixture's constants are the reference's own numbers
+    c = env.constants[0]
+    np.testing.assert_allclose([c.original_area, c.est_min_l, c.est_crit_l], tr["consts"][[0, 2, 3]], rtol=1e-13)
+    obs = env.reset().cpu().numpy()[0]
+    np.testing.assert_array_equal(obs, tr["reset_obs"])
+    st = env.get_state(0)
+    np.testing.assert_array_equal(st["cand_order_ids"], tr["reset_cand_ids"])
+    np.testing.assert_array_equal(st["cand_order_keys"], tr["reset_cand_keys"])
+    assert st["ref_id"] == int(tr["reset_ref_id"])
+    T = len(tr["actions"])
+    n0 = len(pts)
+    acts = torch.from_numpy(tr["actions"]).cuda()
+    max_obs_err = 0.0
+    max_rew_err = 0.0
+    for t in range(T):
+        o, r, d, cpl = env.step(acts[t:t + 1])
+        o = o.cpu().numpy()[0]
+        r = float(r.cpu()[0]); d = bool(d.cpu()[0]); cpl = bool(cpl.cpu()[0])
+        st = env.get_state(0)
+        none = bool(st["status"] & 1)
+        assert none == bool(tr["obs_none"][t]), t
+        if not none:
+            err = float(np.max(np.abs(o.astype(np.float64) - tr["obs"][t])))
+            max_obs_err = max(max_obs_err, err)
+            assert err <= TOL, (t, o, tr["obs"][t])
+            assert st["ref_id"] == tr["ref_id"][t], t
+        rerr = abs(r - tr["reward"][t])
+        max_rew_err = max(max_rew_err, rerr)
+        assert rerr <= TOL, (t, r, tr["reward"][t])
+        assert d == bool(tr["done"][t]) and cpl == bool(tr["complete"][t]), t
+        n = int(tr["ring_len"][t])
+        assert st["n"] == n, t
+        np.testing.assert_array_equal(st["ring_ids"], tr["ring_ids"][t, :n], err_msg=f"ring step {t}")
+        assert st["n_elem"] == tr["n_elem"][t] and st["failed_num"] == tr["failed_num"][t], t
+        assert abs(st["current_area"] - tr["current_area"][t]) <= 1e-9, t
+        m = min(int(tr["n_cand"][t]), n0)
+        assert len(st["cand_order_ids"]) == tr["n_cand"][t], t
+        np.testing.assert_array_equal(st["cand_order_ids"][:m], tr["cand_ids"][t, :m], err_msg=f"cand step {t}")
+        np.testing.assert_allclose(st["cand_order_keys"][:m], tr["cand_keys"][t, :m], rtol=0, atol=1e-9)
+        if not np.isnan(tr["new_xy"][t, 0]):
+            _, vxy = env.get_elements(0)
+            np.testing.assert_array_equal(vxy[st["n_vert"] - 1], tr["new_xy"][t])
+        if d and tr["auto_reset"]:
+            env.reset()
+    env.close()
+    print(f"{name}: max obs err {max_obs_err:.3g}, max reward err {max_rew_err:.3g}")
+
+
+def _run_lockstep(torch, domains, env_domain, actions, check_every=64, sample=64, rollout=False):
+    """Step the HIP env and the CPU oracle on the same [T,n,3] actions; compare everything."""
+    from oracle.ref_lib import RefBatch, RefEnv
+    from reinforcementlearning4meshgeneration_amd.vec_env import MeshVecEnv
+
+    n = len(env_domain)
+    T = actions.shape[0]
+    env = MeshVecEnv(domains, env_domain=env_domain, auto_reset=True, log_capacity=0)
+    consts = env.constants
+    refs = [RefEnv(np.asarray(domains[d], np.float64), consts[d].original_area, consts[d].est_min_l,
+                   consts[d].est_crit_l, cap_new=64) for d in env_domain]
+    batch = RefBatch(refs)
+    obs_ref = batch.reset().copy()
+    obs = env.reset().cpu().numpy()
+    np.testing.assert_array_equal(obs, obs_ref)
+    acts_dev = torch.from_numpy(actions).cuda()
+    stats = dict(obs_mismatch=0, obs_total=0, max_obs=0.0, max_rew=0.0, valid=0, done=0)
+    if rollout:
+        _, rew_all, done_all, comp_all = env.rollout(acts_dev)
+        rew_all = rew_all.cpu().numpy(); done_all = done_all.cpu().numpy(); comp_all = comp_all.cpu().numpy()
+    rng = np.random.default_rng(0)
+    for t in range(T):
+        o_ref, r_ref, d_ref, c_ref = batch.step(actions[t], auto_reset=True, threads=8)
+        if rollout:
+            r, d, c = rew_all[t], done_all[t], comp_all[t]
+        else:
+            o, r, d, c = env.step(acts_dev[t])
+            o = o.cpu().numpy(); r = r.cpu().numpy(); d = d.cpu().numpy(); c = c.cpu().numpy()
+            diff = np.abs(o.astype(np.float64) - o_ref)
+            stats["obs_mismatch"] += int((o != o_ref).sum())
+            stats["obs_total"] += o.size
+            stats["max_obs"] = max(stats["max_obs"], float(diff.max()))
+            assert diff.max() <= TOL, (t, np.unravel_index(diff.argmax(), diff.shape))
+        np.testing.assert_array_equal(d, d_ref, err_msg=f"done step {t}")
+        np.testing.assert_array_equal(c, c_ref, err_msg=f"complete step {t}")
+        rerr = float(np.abs(r - r_ref).max())
+        stats["max_rew"] = max(stats["max_rew"], rerr)
+        assert rerr <= TOL, (t, int(np.abs(r - r_ref).argmax()))
+        stats["done"] += int(d_ref.sum())
+        if not rollout and (t % check_every == check_every - 1 or t == T - 1):
+            for k in rng.choice(n, size=min(sample, n), replace=False):
+                st = env.get_state(int(k))
+                ids, xy = refs[k].ring()
+                np.testing.assert_array_equal(st["ring_ids"], ids, err_msg=f"ring env {k} step {t}")
+                np.testing.assert_array_equal(st["ring_xy"], xy, err_msg=f"ring xy env {k} step {t}")
+                cid, ckey = refs[k].candidates()
+                np.testing.assert_array_equal(st["cand_order_ids"], cid, err_msg=f"cand env {k} step {t}")
+                sc = refs[k].scalars()
+                assert st["n_elem"] == sc["n_elem"] and st["failed_num"] == sc["failed_num"]
+                assert st["ref_id"] == refs[k].ref_id()
+    if rollout:
+        o = env.obs.cpu().numpy()
+        assert np.abs(o.astype(np.float64) - batch.obs).max() <= TOL
+    cnt = env.counters()
+    stats["valid"] = cnt["valid"]
+    assert cnt["steps"] == T * n
+    env.close()
+    return stats
+
+
+def test_config2_4096_boundary_envs_step_parity(torch_cuda):
+    """BASELINE.json configs[1]: 4096 vectorised boundary() envs, random policy, step parity vs CPU."""
+    from reinforcementlearning4meshgeneration_amd.domains import boundary
+    n, T = 4096, 256
+    rng = np.random.default_rng(1)
+    actions = rng.uniform([-1, -1.5, 0], [1, 1.5, 1.5], size=(T, n, 3)).astype(np.float32)
+    st = _run_lockstep(torch_cuda, [boundary(0)], np.zeros(n, np.int32), actions)
+    print("config2:", st)
+    assert st["valid"] > 0.05 * n * T
+    assert st["obs_mismatch"] <= 1e-6 * st["obs_total"]
+
+
+def test_rollout_kernel_equals_stepwise(torch_cuda):
+    """meshenv_rollout (T steps in one launch) must equal T meshenv_step launches."""
+    from reinforcementlearning4meshgeneration_amd.domains import boundary
+    n, T = 512, 128
+    rng = np.random.default_rng(5)
+    actions = rng.uniform([-1, -1.5, 0], [1, 1.5, 1.5], size=(T, n, 3)).astype(np.float32)
+    st = _run_lockstep(torch_cuda, [boundary(0)], np.zeros(n, np.int32), actions, rollout=True)
+    print("rollout:", st)
+
+
+def test_mixed_ragged_domains(torch_cuda):
+    """Ragged rings: several domains of different sizes in one batch (configs[3]/[4] shape at small scale)."""
+    from reinforcementlearning4meshgeneration_amd.domains import boundary, random_domain
+    doms = [boundary(0), boundary(1), boundary(2), boundary(-1)] + [random_domain(100 + k) for k in range(12)]
+    n, T = 256, 200
+    env_domain = (np.arange(n) % len(doms)).astype(np.int32)
+    rng = np.random.default_rng(9)
+    a = rng.uniform([-1, -1.5, 0], [1, 1.5, 1.5], size=(T, n, 3))
+    pick = rng.random((T, n)) < 0.5
+    b = np.stack([rng.uniform(-1, 1, (T, n)), rng.uniform(0.2, 1.0, (T, n)), rng.uniform(0.3, 1.2, (T, n))], axis=2)
+    a[pick] = b[pick]
+    st = _run_lockstep(torch_cuda, doms, env_domain, a.astype(np.float32), check_every=50, sample=256)
+    print("mixed:", st)

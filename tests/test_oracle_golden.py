@@ -1,0 +1,65 @@
+"""CPU: the C oracle (oracle/meshenv_ref.c) against the golden traces recorded from the reference itself
+(oracle/gen_golden.py).  Bit-exact: observations, rewards, flags, ring topology, candidate list, new vertices."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, golden_names
+from oracle.ref_lib import RefEnv
+
+
+def replay(tr, check_candidates=True):
+    c = tr["consts"]
+    env = RefEnv(tr["domain_xy"], c[0], c[2], c[3])
+    obs, none = env.reset()
+    assert not none
+    np.testing.assert_array_equal(obs, tr["reset_obs"])
+    ids, keys = env.candidates()
+    np.testing.assert_array_equal(ids, tr["reset_cand_ids"])
+    np.testing.assert_array_equal(keys, tr["reset_cand_keys"])
+    assert env.ref_id() == int(tr["reset_ref_id"])
+    n0 = tr["domain_xy"].shape[0]
+    for t in range(len(tr["actions"])):
+        obs, rew, done, comp, none = env.step(tr["actions"][t])
+        assert none == bool(tr["obs_none"][t]), t
+        if not none:
+            np.testing.assert_array_equal(obs, tr["obs"][t], err_msg=f"obs step {t}")
+        assert rew == tr["reward"][t], (t, rew, tr["reward"][t])
+        assert done == bool(tr["done"][t]) and comp == bool(tr["complete"][t]), t
+        rids, _ = env.ring()
+        n = int(tr["ring_len"][t])
+        assert len(rids) == n, t
+        np.testing.assert_array_equal(rids, tr["ring_ids"][t, :n], err_msg=f"ring step {t}")
+        if not none:
+            assert env.ref_id() == tr["ref_id"][t], t
+        sc = env.scalars()
+        assert sc["n_elem"] == tr["n_elem"][t] and sc["failed_num"] == tr["failed_num"][t], t
+        assert sc["current_area"] == tr["current_area"][t], t
+        if check_candidates:
+            ids, keys = env.candidates()
+            m = min(int(tr["n_cand"][t]), n0)
+            assert len(ids) == tr["n_cand"][t], t
+            np.testing.assert_array_equal(ids[:m], tr["cand_ids"][t, :m], err_msg=f"cand ids step {t}")
+            np.testing.assert_array_equal(keys[:m], tr["cand_keys"][t, :m], err_msg=f"cand keys step {t}")
+        if not np.isnan(tr["new_xy"][t, 0]):
+            _, vxy = env.elements()
+            np.testing.assert_array_equal(vxy[sc["n_vert"] - 1], tr["new_xy"][t])
+        if done and tr["auto_reset"]:
+            env.reset()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_reference_trace(name):
+    tr = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    replay(tr)
+
+
+def test_golden_covers_edge_cases():
+    """The fixture set must exercise the episode-control paths the reference has."""
+    trs = [dict(np.load(os.path.join(GOLDEN_DIR, n + ".npz"))) for n in golden_names()]
+    assert any(((t["done"] == 1) & (t["complete"] == 0)).any() for t in trs), "no 100-failure truncation"
+    assert any(((t["done"] == 1) & (t["complete"] == 1)).any() for t in trs), "no completed episode"
+    assert any(t["obs_none"].any() for t in trs), "no None observation"
+    assert any((t["ring_len"] == 4).any() for t in trs) and any((t["ring_len"] == 5).any() for t in trs)
+    assert any((~np.isnan(t["new_xy"][:, 0])).any() for t in trs)
