@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/sec of the vectorised BoudaryEnv hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 4096 independent boundary() environments per GPU, uniform-random
+policy (actions pre-generated and resident in HBM), auto-reset on.  A "step" is one vector step = one
+meshenv_step kernel launch over all 4096 envs.  For N > 1 every rank owns 4096 envs (weak scaling) and each
+step ends with one RCCL all-gather of the packed (obs | reward | done | complete) message, the only exchange
+the path has (a central learner needs the gathered observation batch).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def algorithmic_bytes(steps, valid, sum_ring, sum_ring_valid):
+    """every step reads ring coords (16n) + candidate keys (8n) + stamps/flags (4n) and
+    moves 158 B of scalars/action/obs/reward/flags; a valid extraction rewrites the ring (28n) + 48 B."""
+    return 28 * sum_ring + 158 * steps + 28 * sum_ring_valid + 48 * valid
+
+
+def cpu_baseline(n_envs, seed, budget_s=12.0):
+    """The CPU oracle (oracle/meshenv_ref.c, plain C, host libm) on the same workload, bounded sample."""
+    from oracle.ref_lib import RefBatch, RefEnv
+    from reinforcementlearning4meshgeneration_amd.domains import boundary
+
+    envs = [RefEnv.from_points(boundary(0), cap_new=64) for _ in range(n_envs)]
+    batch = RefBatch(envs)
+    batch.reset()
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array([-1, -1.5, 0.0]), np.array([1, 1.5, 1.5])
+
+    def run(T, threads):
+        acts = rng.uniform(lo, hi, size=(T, n_envs, 3)).astype(np.float32)
+        t0 = time.perf_counter()
+        for t in range(T):
+            batch.step(acts[t], auto_reset=True, threads=threads)
+        return time.perf_counter() - t0
+
+    dt = run(4, 1)  # calibrate
+    T1 = max(8, min(2000, int(0.5 * budget_s / (dt / 4))))
+    dt1 = run(T1, 1)
+    one = n_envs * T1 / dt1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, int(os.environ.get("MESHENV_CPU_THREADS", "16"))))
+    dtc = run(2, cores)
+    Tn = max(8, min(4000, int(0.5 * budget_s / (dtc / 2))))
+    dtn = run(Tn, cores)
+    allc = n_envs * Tn / dtn
+    return dict(value=one, unit="env-steps/s", cores=1, kind="port",
+                sample=f"{n_envs} boundary() envs x {T1} uniform-random vector steps, oracle/meshenv_ref.c, 1 thread",
+                all_cores=dict(value=allc, cores=cores, sample=f"{n_envs} envs x {Tn} steps, OpenMP over envs"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from reinforcementlearning4meshgeneration_amd.domains import boundary
+    from reinforcementlearning4meshgeneration_amd.vec_env import MeshVecEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n, K, W = args.envs, args.steps, args.warmup
+    env = MeshVecEnv([boundary(0)], n_envs=n, device=local_rank, auto_reset=True, log_capacity=0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    lo = torch.tensor([-1.0, -1.5, 0.0], device=dev)
+    hi = torch.tensor([1.0, 1.5, 1.5], device=dev)
+    actions = (lo + (hi - lo) * torch.rand((K + W, n, 3), device=dev, generator=gen)).to(torch.float32).contiguous()
+
+    # packed exchange message for N > 1: [obs(18) | reward | done | complete] per env, float32
+    if world > 1:
+        msg = torch.empty((n, 21), dtype=torch.float32, device=dev)
+        gathered = torch.empty((world * n, 21), dtype=torch.float32, device=dev)
+
+    def one_step(t):
+        obs, rew, done, comp = env.step(actions[t])
+        if world > 1:
+            msg[:, :18] = obs
+            msg[:, 18] = rew
+            msg[:, 19] = done
+            msg[:, 20] = comp
+            dist.all_gather_into_tensor(gathered, msg)
+
+    for t in range(W):
+        one_step(t)
+    torch.cuda.synchronize()
+    c0 = env.counters()
+    if not args.no_kernel_timing:
+        env.set_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        one_step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    kt = None
+    if not args.no_kernel_timing:
+        kt = env.kernel_times_ms()
+        env.set_timing(False)
+    c1 = env.counters()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    d = {k: c1[k] - c0[k] for k in c0}
+    assert d["steps"] == K * n, (d, K, n)
+    total_steps = K * n * world
+    value = total_steps / elapsed
+    out = {
+        "metric": "env-steps/sec at N_envs=4096 per GPU, boundary() domain",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{n} vectorised boundary() envs per GPU (general/polygon.py:79-83, 30-vertex ring), "
+                               "uniform-random float32 actions resident in HBM, auto-reset, one meshenv_step launch "
+                               "per vector step" + (", + RCCL all-gather of [n,21] f32 obs/reward/done message" if world > 1 else ""),
+                   "n_envs_per_gpu": n, "n_envs_total": n * world, "parallelism": f"env-shard x{world}",
+                   "valid_action_rate": d["valid"] / max(1, d["steps"]), "mean_ring_len": d["sum_ring"] / max(1, d["steps"])},
+    }
+    if kt is not None and len(kt):
+        alg = algorithmic_bytes(d["steps"], d["valid"], d["sum_ring"], d["sum_ring_valid"]) / K
+        avg_ms = float(np.mean(kt))
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "meshenv::k_step", "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": float(np.min(kt)) * 1e3,
+                           "algorithmic_bytes_per_launch": alg, "launches_timed": int(len(kt))}
+    env.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, seed=99)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

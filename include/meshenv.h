@@ -176,10 +176,16 @@ int meshenv_get_elements(MeshEnv *h, int env, int32_t *quads_host, int cap_elems
  */
 int meshenv_counters(MeshEnv *h, uint64_t *out_host);
 
-/* Duration in milliseconds of the most recent step/rollout kernel, measured with HIP events on the
- * handle's stream (synchronises).  Enabled with meshenv_set_timing(h, 1). */
+/*
+ * Per-launch kernel timing with HIP events recorded on the handle's stream around every
+ * meshenv_step / meshenv_rollout launch (bench.py's roofline figure).  meshenv_set_timing(h, 1)
+ * arms a pool of MESHENV_TIMING_POOL event pairs and clears the record; meshenv_kernel_times()
+ * synchronises and copies the durations (milliseconds, launch order) of the launches recorded since
+ * then -- at most the newest MESHENV_TIMING_POOL of them -- into ms_host[cap] and clears the record.
+ */
+#define MESHENV_TIMING_POOL 4096
 int meshenv_set_timing(MeshEnv *h, int enable);
-int meshenv_last_kernel_ms(MeshEnv *h, float *ms_host);
+int meshenv_kernel_times(MeshEnv *h, float *ms_host, int cap, int32_t *n_out);
 
 #ifdef __cplusplus
 }

@@ -31,8 +31,8 @@ struct MeshEnv {
     std::vector<void *> allocs;
     std::string err;
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
+    std::vector<hipEvent_t> ev;  // 2 * MESHENV_TIMING_POOL events, created on first use
+    long long ev_count = 0;      // launches recorded since timing was armed
     uint8_t *status_tmp = nullptr;
 };
 
@@ -108,8 +108,7 @@ void meshenv_destroy(MeshEnv *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) (void)hipFree(p);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -263,8 +262,6 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
     CREATE_HIP(hipMemcpy(d_dom_const, dc.data(), sizeof(DomConst) * (size_t)n_domains, hipMemcpyHostToDevice));
     CREATE_HIP(hipMemcpy(d_env_off, h->env_off_host.data(), sizeof(int32_t) * ((size_t)n_envs + 1), hipMemcpyHostToDevice));
     CREATE_HIP(hipMemcpy(S.scal, sc.data(), sizeof(EnvScalars) * (size_t)n_envs, hipMemcpyHostToDevice));
-    CREATE_HIP(hipEventCreate(&h->ev0));
-    CREATE_HIP(hipEventCreate(&h->ev1));
 
     hipLaunchKernelGGL(k_init_domains, dim3(n_domains), dim3(64), lds, h->stream, S, cap);
     CREATE_HIP(hipGetLastError());
@@ -303,13 +300,14 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
     if (!h) return MESHENV_E_ARG;
     if (!actions_dev || !obs_dev || !reward_dev || !done_dev || !complete_dev) return fail_arg(h, "meshenv_step: null device pointer");
     if (n_steps <= 0) return fail_arg(h, "meshenv_rollout: n_steps must be positive");
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    const size_t slot = (size_t)(h->ev_count % MESHENV_TIMING_POOL);
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2 * slot], h->stream));
     hipLaunchKernelGGL(k_step, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, n_steps, actions_dev, obs_dev,
                        reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) {
-        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-        h->ev_valid = true;
+        HIP_TRY(h, hipEventRecord(h->ev[2 * slot + 1], h->stream));
+        h->ev_count += 1;
     }
     return MESHENV_OK;
 }
@@ -445,20 +443,30 @@ int meshenv_counters(MeshEnv *h, uint64_t *out_host)
 int meshenv_set_timing(MeshEnv *h, int enable)
 {
     if (!h) return MESHENV_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (enable && h->ev.empty()) {
+        h->ev.resize(2 * (size_t)MESHENV_TIMING_POOL, nullptr);
+        for (hipEvent_t &e : h->ev) HIP_TRY(h, hipEventCreate(&e));
+    }
     h->timing = enable != 0;
-    h->ev_valid = false;
+    h->ev_count = 0;
     return MESHENV_OK;
 }
 
-int meshenv_last_kernel_ms(MeshEnv *h, float *ms_host)
+int meshenv_kernel_times(MeshEnv *h, float *ms_host, int cap, int32_t *n_out)
 {
-    if (!h || !ms_host) return MESHENV_E_ARG;
-    if (!h->ev_valid) {
-        h->err = "meshenv_last_kernel_ms: timing not enabled or no step launched yet";
-        return MESHENV_E_STATE;
+    if (!h || !ms_host || !n_out || cap < 0) return MESHENV_E_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    long long have = h->ev_count < MESHENV_TIMING_POOL ? h->ev_count : MESHENV_TIMING_POOL;
+    if (have > cap) have = cap;
+    const long long first = h->ev_count - have;
+    for (long long k = 0; k < have; k++) {
+        const size_t slot = (size_t)((first + k) % MESHENV_TIMING_POOL);
+        HIP_TRY(h, hipEventElapsedTime(ms_host + k, h->ev[2 * slot], h->ev[2 * slot + 1]));
     }
-    HIP_TRY(h, hipEventSynchronize(h->ev1));
-    HIP_TRY(h, hipEventElapsedTime(ms_host, h->ev0, h->ev1));
+    *n_out = (int32_t)have;
+    h->ev_count = 0;
     return MESHENV_OK;
 }
 

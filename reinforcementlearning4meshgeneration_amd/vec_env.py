@@ -253,10 +253,13 @@ class MeshVecEnv:
     def set_timing(self, enable: bool):
         self._check(self._L.meshenv_set_timing(self._handle, 1 if enable else 0), "meshenv_set_timing")
 
-    def last_kernel_ms(self) -> float:
-        ms = C.c_float(0)
-        self._check(self._L.meshenv_last_kernel_ms(self._handle, C.byref(ms)), "meshenv_last_kernel_ms")
-        return float(ms.value)
+    def kernel_times_ms(self) -> np.ndarray:
+        """Durations (ms) of the step/rollout launches recorded since set_timing(True) / the last call."""
+        buf = np.zeros(4096, np.float32)
+        n = C.c_int32(0)
+        self._check(self._L.meshenv_kernel_times(self._handle, buf.ctypes.data, len(buf), C.byref(n)),
+                    "meshenv_kernel_times")
+        return buf[:n.value].copy()
 
     # ------------------------------------------------------------------ SB3 VecEnv-shaped API (numpy)
     def step_async(self, actions):
