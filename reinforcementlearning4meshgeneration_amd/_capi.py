@@ -44,11 +44,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MESHENV_LIB", LIB_PATH)  # A/B builds of the same library
+    if not os.path.exists(path):
         raise MeshEnvError(
-            f"{LIB_PATH} is missing: build it with `python -m reinforcementlearning4meshgeneration_amd.build` "
+            f"{path} is missing: build it with `python -m reinforcementlearning4meshgeneration_amd.build` "
             "(hipcc, gfx950).  This package has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32p, f64p, u8p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p, C.c_void_p
     L.meshenv_default_params.argtypes = [C.POINTER(MeshEnvParams)]
     L.meshenv_default_params.restype = None

@@ -9,6 +9,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef MESHENV_NOINLINE
+#define MESHENV_NOINLINE __noinline__
+#endif
+
 namespace meshenv {
 
 constexpr double kPi = 3.141592653589793;  // math.pi
@@ -51,6 +55,22 @@ __device__ __forceinline__ double round4_np(double x) { return rint(x * 1e4) / 1
 // round(np.float32, 4): the same in float32
 __device__ __forceinline__ float round4_npf(float x) { return rintf(x * 1e4f) / 1e4f; }
 
+// ---------------------------------------------------------------------------------- transcendentals
+// One out-of-line copy of each libm-style routine: the kernels evaluate them for a handful of lanes per
+// call site ("job lanes"), so sharing the body keeps the kernel inside the instruction cache.
+__device__ MESHENV_NOINLINE double atan2_nc(double y, double x) { return atan2(y, x); }
+struct SinCos {
+    double s, c;
+};
+__device__ MESHENV_NOINLINE SinCos sincos_nc(double a)
+{
+    SinCos r;
+    r.s = sin(a);
+    r.c = cos(a);
+    return r;
+}
+__device__ MESHENV_NOINLINE double sin_nc(double a) { return sin(a); }
+
 // ---------------------------------------------------------------------------------- primitives
 // Point2D.distance_to, C:17-18.  (The reference's `** 2` is libm pow(x, 2.0), which differs from x*x by
 // one ulp for 0.085 % of doubles; the device uses the exactly rounded product -- see DESIGN.md.)
@@ -69,18 +89,19 @@ __device__ __forceinline__ void cw_terms(P2 s, P2 p1, P2 p2, double &c, double &
     d = v1x * v2x + v1y * v2y;
 }
 
-__device__ __forceinline__ double cw_from_terms(double c, double d)
+// tail of Vertex.to_find_clockwise_angle given t = atan2(c, d): theta = -t, quantised to 1e-4 rad in [0, 2pi]
+__device__ __forceinline__ double cw_finish(double t)
 {
-    const double theta = -atan2(c, d);
+    const double theta = -t;
     return signbit(theta) ? round4_py(2 * kPi + theta) : round4_py(theta);
 }
 
-// Vertex.to_find_clockwise_angle, C:91-100: angle in [0, 2pi] quantised to 1e-4 rad
+// Vertex.to_find_clockwise_angle, C:91-100
 __device__ __forceinline__ double cw(P2 s, P2 p1, P2 p2)
 {
     double c, d;
     cw_terms(s, p1, p2, c, d);
-    return cw_from_terms(c, d);
+    return cw_finish(atan2_nc(c, d));
 }
 
 // True when round(sin(cw(...)), 4) can only be non-zero.  The rounded angle is within 5e-5 rad of the
@@ -88,21 +109,29 @@ __device__ __forceinline__ double cw(P2 s, P2 p1, P2 p2)
 // the rounded one is at least 9.5e-4 away and |sin| >= 9.4e-4, which rounds to a non-zero 4-decimal
 // value.  Lets Segment.straddle skip atan2/sin for every non-degenerate configuration; the exact path is
 // taken otherwise, so results are identical to the unfiltered evaluation.
-__device__ __forceinline__ bool surely_not_collinear(double c, double d) { return fabs(c) > 1e-3 * fabs(d); }
+__device__ __forceinline__ bool surely_not_collinear(double c, double d)
+{
+#ifdef MESHENV_NO_FILTERS
+    (void)c; (void)d;
+    return false;
+#else
+    return fabs(c) > 1e-3 * fabs(d);
+#endif
+}
 
 // cross_product, C:482-483
 __device__ __forceinline__ double crossp(double ax, double ay, double bx, double by) { return ax * by - bx * ay; }
 
 // Segment.straddle, C:491-516; self = (p1,p2), another = (q1,q2)
-__device__ __noinline__ bool straddle(P2 p1, P2 p2, P2 q1, P2 q2)
+__device__ MESHENV_NOINLINE bool straddle(P2 p1, P2 p2, P2 q1, P2 q2)
 {
     double c1, d1, c2, d2;
     cw_terms(p1, q1, p2, c1, d1);
     cw_terms(p1, q2, p2, c2, d2);
     bool collinear = false;
     if (!surely_not_collinear(c1, d1) && !surely_not_collinear(c2, d2)) {
-        const double s1 = round4_py(sin(cw_from_terms(c1, d1)));
-        const double s2 = round4_py(sin(cw_from_terms(c2, d2)));
+        const double s1 = round4_py(sin_nc(cw_finish(atan2_nc(c1, d1))));
+        const double s2 = round4_py(sin_nc(cw_finish(atan2_nc(c2, d2))));
         collinear = (s1 == s2) && (s2 == 0.0);
     }
     if (collinear) {
@@ -142,75 +171,164 @@ __device__ __forceinline__ double seg_point_distance(P2 p1, P2 p2, P2 v)
 // ---------------------------------------------------------------------------------- wave helpers (64 lanes)
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-__device__ __forceinline__ double shfl_xor_f64(double v, int m)
+// value of lane `l` (wave-uniform l) as a scalar; v_readlane instead of an LDS-crossbar shuffle
+__device__ __forceinline__ int lane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float lane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_f64(double v, int l)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_xor(lo, m, 64);
-    hi = __shfl_xor(hi, m, 64);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double bcast_f64(double v, int src)
+// DPP building block: lanes whose source is outside the row / masked row keep `identity`
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_i32(int identity, int v)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl(lo, src, 64);
-    hi = __shfl(hi, src, 64);
+    return __builtin_amdgcn_update_dpp(identity, v, kCtrl, kRowMask, 0xf, false);
+}
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_f64(double identity, double v)
+{
+    const int lo = dpp_i32<kCtrl, kRowMask>(__double2loint(identity), __double2loint(v));
+    const int hi = dpp_i32<kCtrl, kRowMask>(__double2hiint(identity), __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+
+constexpr int kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118;
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+
+#define MESHENV_DPP_REDUCE(STEP)              \
+    STEP(kDppShr1, 0xf)                       \
+    STEP(kDppShr2, 0xf)                       \
+    STEP(kDppShr4, 0xf)                       \
+    STEP(kDppShr8, 0xf)                       \
+    STEP(kDppBcast15, 0xa)                    \
+    STEP(kDppBcast31, 0xc)
+
+constexpr double kInf = __builtin_huge_val();
 
 // wave-wide argmin of (v, ord): smallest v, ties -> smallest ord.  Lanes without a candidate pass
-// v = +inf (and any ord).  Every lane receives the result.
+// v = +inf.  The result is wave-uniform (read from lane 63 after a DPP scan).
 __device__ __forceinline__ void wave_argmin_f64(double &v, int &ord)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ov = shfl_xor_f64(v, m);
-        const int oo = __shfl_xor(ord, m, 64);
-        if (ov < v || (ov == v && oo < ord)) {
-            v = ov;
-            ord = oo;
-        }
+#define STEP(CTRL, MASK)                                                        \
+    {                                                                           \
+        const double ov = dpp_f64<CTRL, MASK>(kInf, v);                         \
+        const int oo = dpp_i32<CTRL, MASK>(0x7fffffff, ord);                    \
+        if (ov < v || (ov == v && oo < ord)) { v = ov; ord = oo; }              \
     }
+    MESHENV_DPP_REDUCE(STEP)
+#undef STEP
+    v = lane_f64(v, 63);
+    ord = lane_i32(ord, 63);
 }
 
 __device__ __forceinline__ void wave_argmin_f32(float &v, int &ord)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float ov = __shfl_xor(v, m, 64);
-        const int oo = __shfl_xor(ord, m, 64);
-        if (ov < v || (ov == v && oo < ord)) {
-            v = ov;
-            ord = oo;
-        }
+#define STEP(CTRL, MASK)                                                                                  \
+    {                                                                                                     \
+        const float ov = __int_as_float(dpp_i32<CTRL, MASK>(0x7f800000, __float_as_int(v)));              \
+        const int oo = dpp_i32<CTRL, MASK>(0x7fffffff, ord);                                              \
+        if (ov < v || (ov == v && oo < ord)) { v = ov; ord = oo; }                                        \
     }
+    MESHENV_DPP_REDUCE(STEP)
+#undef STEP
+    v = lane_f32(v, 63);
+    ord = lane_i32(ord, 63);
 }
 
 __device__ __forceinline__ double wave_min_f64(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ov = shfl_xor_f64(v, m);
-        v = ov < v ? ov : v;
+#define STEP(CTRL, MASK)                                        \
+    {                                                           \
+        const double ov = dpp_f64<CTRL, MASK>(kInf, v);         \
+        v = ov < v ? ov : v;                                    \
     }
-    return v;
+    MESHENV_DPP_REDUCE(STEP)
+#undef STEP
+    return lane_f64(v, 63);
 }
 
-__device__ __forceinline__ int wave_min_i32(int v)
+typedef unsigned long long u64;
+
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ u64 dpp_u64(u64 identity, u64 v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const int ov = __shfl_xor(v, m, 64);
-        v = ov < v ? ov : v;
-    }
-    return v;
+    const unsigned lo = (unsigned)dpp_i32<kCtrl, kRowMask>((int)(unsigned)identity, (int)(unsigned)v);
+    const unsigned hi = (unsigned)dpp_i32<kCtrl, kRowMask>((int)(unsigned)(identity >> 32), (int)(unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
 }
 
-__device__ __forceinline__ int wave_sum_i32(int v)
+__device__ __forceinline__ u64 lane_u64(u64 v, int l)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
 }
+
+// Five independent unsigned 64-bit min-reductions in one DPP scan (the chains interleave, hiding the DPP
+// and compare latencies).  Non-negative floats/doubles order like their bit patterns, so (value, order)
+// pairs packed as (bits << 32 | order) reduce to the first-in-order minimum in one pass.
+__device__ __forceinline__ void wave_min5_u64(u64 &a, u64 &b, u64 &c, u64 &d, u64 &e)
+{
+#define STEP(CTRL, MASK)                                        \
+    {                                                           \
+        const u64 oa = dpp_u64<CTRL, MASK>(~0ULL, a);           \
+        const u64 ob = dpp_u64<CTRL, MASK>(~0ULL, b);           \
+        const u64 oc = dpp_u64<CTRL, MASK>(~0ULL, c);           \
+        const u64 od = dpp_u64<CTRL, MASK>(~0ULL, d);           \
+        const u64 oe = dpp_u64<CTRL, MASK>(~0ULL, e);           \
+        a = oa < a ? oa : a;                                    \
+        b = ob < b ? ob : b;                                    \
+        c = oc < c ? oc : c;                                    \
+        d = od < d ? od : d;                                    \
+        e = oe < e ? oe : e;                                    \
+    }
+    MESHENV_DPP_REDUCE(STEP)
+#undef STEP
+    a = lane_u64(a, 63);
+    b = lane_u64(b, 63);
+    c = lane_u64(c, 63);
+    d = lane_u64(d, 63);
+    e = lane_u64(e, 63);
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#define STEP(CTRL, MASK)                                                        \
+    {                                                                           \
+        const unsigned ov = (unsigned)dpp_i32<CTRL, MASK>(-1, (int)v);          \
+        v = ov < v ? ov : v;                                                    \
+    }
+    MESHENV_DPP_REDUCE(STEP)
+#undef STEP
+    return (unsigned)lane_i32((int)v, 63);
+}
+
+// sign/zero of round(x, 4) without the final division: returns 1e4 * round(x, 4) as an integer-valued
+// double carrying x's sign (tests `== 0`, `< 0` and sign-of-product are unchanged by the exact scaling)
+__device__ __forceinline__ double round4_py_scaled(double x)
+{
+    const double ax = fabs(x);
+    const double y = ax * 1e4;
+    if (!(y < 4503599627370496.0)) return x;
+    const double e = fma(ax, 1e4, -y);
+    const double f = floor(y);
+    const double t = (y - f) - 0.5;
+    const double s = t + e;
+    double r = f;
+    if (s > 0.0) r = f + 1.0;
+    else if (s == 0.0 && (((long long)f) & 1LL)) r = f + 1.0;
+    return copysign(r, x);
+}
+__device__ __forceinline__ double round4_np_scaled(double x) { return rint(x * 1e4); }
 
 }  // namespace meshenv

@@ -27,13 +27,12 @@ struct MeshEnv {
     DevState S{};
     int n_envs = 0, n_domains = 0, cap = 0, max_ring = 0;
     size_t lds = 0;
-    std::vector<int32_t> env_off_host, dom_off_host, env_dom_host;
+    std::vector<int32_t> dom_off_host, env_dom_host;
     std::vector<void *> allocs;
     std::string err;
     bool timing = false;
     std::vector<hipEvent_t> ev;  // 2 * MESHENV_TIMING_POOL events, created on first use
     long long ev_count = 0;      // launches recorded since timing was armed
-    uint8_t *status_tmp = nullptr;
 };
 
 namespace {
@@ -203,32 +202,15 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
     const int total_dom = dom_offsets_host[n_domains];
     h->dom_off_host.assign(dom_offsets_host, dom_offsets_host + n_domains + 1);
     h->env_dom_host.assign(env_domain_host, env_domain_host + n_envs);
-    h->env_off_host.resize((size_t)n_envs + 1);
-    h->env_off_host[0] = 0;
-    for (int e = 0; e < n_envs; e++) {
-        const int d = env_domain_host[e];
-        const long long next = (long long)h->env_off_host[e] + (dom_offsets_host[d + 1] - dom_offsets_host[d]);
-        if (next > 0x7fffffffLL) {
-            g_create_error = "meshenv_create: total ring storage exceeds 2^31 vertices";
-            meshenv_destroy(h);
-            return MESHENV_E_ARG;
-        }
-        h->env_off_host[e + 1] = (int32_t)next;
-    }
-    const size_t total_env = (size_t)h->env_off_host[n_envs];
+    const size_t total_env = (size_t)n_envs * (size_t)cap;  // uniform ring stride
+    S.cap = cap;
 
-    int32_t *d_dom_off = nullptr, *d_env_off = nullptr;
     double2 *d_dom_xy = nullptr;
-    DomConst *d_dom_const = nullptr;
-    CREATE_TRY(dev_alloc(h, &d_dom_off, (size_t)n_domains + 1));
+    CREATE_TRY(dev_alloc(h, &S.dom, (size_t)n_domains));
     CREATE_TRY(dev_alloc(h, &d_dom_xy, (size_t)total_dom));
     CREATE_TRY(dev_alloc(h, &S.dom_key, (size_t)total_dom));
     CREATE_TRY(dev_alloc(h, &S.dom_stamp, (size_t)total_dom));
-    CREATE_TRY(dev_alloc(h, &d_dom_const, (size_t)n_domains));
     CREATE_TRY(dev_alloc(h, &S.dom_obs, (size_t)n_domains * kObsDim));
-    CREATE_TRY(dev_alloc(h, &S.dom_ref, (size_t)n_domains));
-    CREATE_TRY(dev_alloc(h, &S.dom_bl, (size_t)n_domains));
-    CREATE_TRY(dev_alloc(h, &d_env_off, (size_t)n_envs + 1));
     CREATE_TRY(dev_alloc(h, &S.ring_xy, total_env));
     CREATE_TRY(dev_alloc(h, &S.ring_id, total_env));
     CREATE_TRY(dev_alloc(h, &S.ring_key, total_env));
@@ -236,32 +218,36 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
     CREATE_TRY(dev_alloc(h, &S.scal, (size_t)n_envs));
     CREATE_TRY(dev_alloc(h, &S.cnt, (size_t)n_envs));
     CREATE_TRY(dev_alloc(h, &S.obs_cache, (size_t)n_envs * kObsDim));
-    CREATE_TRY(dev_alloc(h, &h->status_tmp, (size_t)n_envs));
     if (prm.log_capacity > 0) {
         CREATE_TRY(dev_alloc(h, &S.log_quads, (size_t)n_envs * prm.log_capacity * 4));
         CREATE_TRY(dev_alloc(h, &S.log_vxy, (size_t)n_envs * prm.log_capacity));
     }
-    S.dom_off = d_dom_off;
     S.dom_xy = d_dom_xy;
-    S.dom_const = d_dom_const;
-    S.env_off = d_env_off;
+#ifdef MESHENV_STAMPS
+    CREATE_TRY(dev_alloc(h, &S.dbg, (size_t)n_envs * 16));
+#endif
 
     std::vector<DomConst> dc((size_t)n_domains);
+    std::memset(dc.data(), 0, dc.size() * sizeof(DomConst));
     for (int d = 0; d < n_domains; d++) {
         dc[d].orig_area = dom_consts_host[3 * d];
         dc[d].min_area = dom_consts_host[3 * d + 1] * dom_consts_host[3 * d + 1];   // estimated_area_range[0] ** 2
         dc[d].crit_area = dom_consts_host[3 * d + 2] * dom_consts_host[3 * d + 2];  // estimated_area_range[1] ** 2
-        dc[d].pad = 0;
+        dc[d].off = dom_offsets_host[d];
+        dc[d].n0 = dom_offsets_host[d + 1] - dom_offsets_host[d];
+        dc[d].ref = -1;
     }
     std::vector<EnvScalars> sc((size_t)n_envs);
     std::memset(sc.data(), 0, sc.size() * sizeof(EnvScalars));
     for (int e = 0; e < n_envs; e++) sc[e].dom = env_domain_host[e];
 
-    CREATE_HIP(hipMemcpy(d_dom_off, dom_offsets_host, sizeof(int32_t) * ((size_t)n_domains + 1), hipMemcpyHostToDevice));
+    CREATE_HIP(hipMemcpy(S.dom, dc.data(), sizeof(DomConst) * (size_t)n_domains, hipMemcpyHostToDevice));
     CREATE_HIP(hipMemcpy(d_dom_xy, dom_xy_host, sizeof(double2) * (size_t)total_dom, hipMemcpyHostToDevice));
-    CREATE_HIP(hipMemcpy(d_dom_const, dc.data(), sizeof(DomConst) * (size_t)n_domains, hipMemcpyHostToDevice));
-    CREATE_HIP(hipMemcpy(d_env_off, h->env_off_host.data(), sizeof(int32_t) * ((size_t)n_envs + 1), hipMemcpyHostToDevice));
     CREATE_HIP(hipMemcpy(S.scal, sc.data(), sizeof(EnvScalars) * (size_t)n_envs, hipMemcpyHostToDevice));
+    CREATE_HIP(hipMemset(S.ring_xy, 0, sizeof(double2) * total_env));
+    CREATE_HIP(hipMemset(S.ring_id, 0, sizeof(int32_t) * total_env));
+    CREATE_HIP(hipMemset(S.ring_key, 0, sizeof(double) * total_env));
+    CREATE_HIP(hipMemset(S.ring_stamp, 0, sizeof(int32_t) * total_env));
 
     hipLaunchKernelGGL(k_init_domains, dim3(n_domains), dim3(64), lds, h->stream, S, cap);
     CREATE_HIP(hipGetLastError());
@@ -350,10 +336,14 @@ int meshenv_get_state(MeshEnv *h, int env, int32_t *ring_ids_host, double *ring_
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     EnvScalars s;
     HIP_TRY(h, hipMemcpy(&s, h->S.scal + env, sizeof(s), hipMemcpyDeviceToHost));
-    const size_t off = (size_t)h->env_off_host[env];
-    const int n0 = h->env_off_host[env + 1] - h->env_off_host[env];
+    const size_t off = (size_t)env * (size_t)h->cap;
+    const int n0 = h->dom_off_host[s.dom + 1] - h->dom_off_host[s.dom];
     const int n = s.n;
-    if (ring_ids_host) HIP_TRY(h, hipMemcpy(ring_ids_host, h->S.ring_id + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (ring_ids_host) {
+        HIP_TRY(h, hipMemcpy(ring_ids_host, h->S.ring_id + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++)  // k-th new vertex -> global id n0 + k (index in boundary.vertices)
+            if (ring_ids_host[i] & kNewBit) ring_ids_host[i] = n0 + (ring_ids_host[i] & ~kNewBit);
+    }
     if (ring_xy_host) HIP_TRY(h, hipMemcpy(ring_xy_host, h->S.ring_xy + off, sizeof(double2) * n, hipMemcpyDeviceToHost));
     if (cand_stamp_host || cand_key_host) {
         std::vector<int32_t> st((size_t)n);
@@ -406,8 +396,11 @@ int meshenv_get_elements(MeshEnv *h, int env, int32_t *quads_host, int cap_elems
     if (ne > cap_elems) ne = cap_elems;
     int nv = n0 + nnew;
     if (nv > cap_verts) nv = cap_verts;
-    if (quads_host && ne > 0)
+    if (quads_host && ne > 0) {
         HIP_TRY(h, hipMemcpy(quads_host, h->S.log_quads + (size_t)env * cap * 4, sizeof(int32_t) * 4 * (size_t)ne, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4 * ne; i++)
+            if (quads_host[i] & kNewBit) quads_host[i] = n0 + (quads_host[i] & ~kNewBit);
+    }
     if (vertex_xy_host && nv > 0) {
         const int first = nv < n0 ? nv : n0;
         HIP_TRY(h, hipMemcpy(vertex_xy_host, h->S.dom_xy + h->dom_off_host[d], sizeof(double2) * (size_t)first, hipMemcpyDeviceToHost));
@@ -439,6 +432,24 @@ int meshenv_counters(MeshEnv *h, uint64_t *out_host)
     out_host[3] = sv;
     return MESHENV_OK;
 }
+
+#ifdef MESHENV_STAMPS
+// diagnostic build only: raw per-env counter records (see k_step)
+int meshenv_debug_raw_counters(MeshEnv *h, uint64_t *out_host)
+{
+    if (!h || !out_host) return MESHENV_E_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out_host, h->S.cnt, sizeof(EnvCounters) * (size_t)h->n_envs, hipMemcpyDeviceToHost));
+    return MESHENV_OK;
+}
+int meshenv_debug_stamps(MeshEnv *h, uint64_t *out_host)
+{
+    if (!h || !out_host) return MESHENV_E_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out_host, h->S.dbg, sizeof(uint64_t) * 16 * (size_t)h->n_envs, hipMemcpyDeviceToHost));
+    return MESHENV_OK;
+}
+#endif
 
 int meshenv_set_timing(MeshEnv *h, int enable)
 {

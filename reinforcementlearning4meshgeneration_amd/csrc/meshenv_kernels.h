@@ -1,16 +1,19 @@
 // meshenv_kernels.h -- wavefront-per-environment HIP kernels of the BoudaryEnv hot path (gfx950 / CDNA4).
 //
 // Execution model: one 64-lane wavefront (= one 64-thread workgroup) owns one environment for the whole
-// launch.  The ring (coords, ids and, when needed, candidate keys/stamps) is staged into LDS with
-// coalesced 16-byte loads; O(n) passes (point-in-polygon, boundary intersection scan, observation scan,
-// boundary-quality scan, candidate selection) run one ring vertex per lane and are combined with
-// ballots / shuffle reductions that carry the reference's sequential first-wins order as (value, order)
-// pairs; O(1) parts (action decode, quad validity, reward) use a handful of lanes for the independent
-// atan2 evaluations and are broadcast.  No MFMA: this is branchy fp64 geometry.
-//
-// A single-wave workgroup makes __syncthreads() a wave-local LDS fence, so phases that hand data between
-// lanes through LDS stay cheap, and wave-uniform control flow (rule type, valid / invalid action) never
-// diverges inside a wave.
+// launch.
+//   * HBM -> LDS: scalars, action and the ring arrays (coords, ids, candidate keys, stamps) are requested in
+//     one burst at kernel entry (uniform ring stride, no dependent offset lookup), 16 B per lane, coalesced.
+//   * O(n) passes (point-in-polygon, boundary intersection scan, observation scan, boundary-quality scan,
+//     candidate selection) run one ring vertex per lane and are combined with ballots and DPP scans that
+//     carry the reference's sequential first-wins order as (value, traversal order) pairs.
+//   * O(1) geometry with several independent atan2/sincos evaluations (quad corner angles, candidate keys,
+//     observation window, action frame) is batched into "job lanes": each stage evaluates all of its
+//     transcendentals in one pass over a few lanes and broadcasts with v_readlane, so the dependent chain of a
+//     valid extraction is 5 atan2 stages + 1 sincos stage instead of ~25 serial calls.
+//   * wave-uniform control flow (rule type, valid / invalid action) never diverges inside a wave, and a
+//     single-wave workgroup makes __syncthreads() a wave-local LDS fence.
+// No MFMA: this is branchy fp64 geometry, not a contraction.
 #pragma once
 
 #include "meshenv_geom.h"
@@ -20,13 +23,25 @@ namespace meshenv {
 
 constexpr int kStNoReference = 1;
 constexpr int kStLogOverflow = 2;
+constexpr int kNewBit = 0x40000000;  // ring_id of the k-th vertex created this episode = kNewBit | k
 
 // scratch area appended to the LDS ring arrays
+#ifdef MESHENV_STAMPS
+#define MESHENV_STAMP(c, k) do { if ((c).lane == 0) (c).sc->stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MESHENV_STAMP(c, k) do { } while (0)
+#endif
+
 struct Scratch {
     double2 q[4];       // quad vertices
     double ang[4];      // quad corner angles
+    double tmp[16];     // job-lane results handed between stages
+    double tmp2[8];     // quad edge / diagonal lengths
     float robs[18];     // observation rows before the final float32 rounding
     int ipad[2];
+#ifdef MESHENV_STAMPS
+    unsigned long long stamps[16];
+#endif
 };
 
 struct Ctx {
@@ -35,13 +50,15 @@ struct Ctx {
     double *key;
     int32_t *stamp;
     int32_t *id;
-    uint8_t *flag;
+    double *ang_ord;   // observation scan: clockwise angle per traversal position
+    int32_t *list;     // compaction list of the boundary intersection scan
     Scratch *sc;
-    // wave-uniform registers
-    int lane, env, off, n0;
+    // wave-uniform
+    int lane, env;
+    size_t base;  // env * cap
     int n, ref, n_elem, failed, n_new, counter, status, dom;
-    double bl, area;
-    bool keys_loaded, ring_dirty;
+    double bl, area, ct, st;
+    bool ring_dirty;
     // lane-private
     float obs;  // lanes 0..17: current observation
 };
@@ -57,7 +74,7 @@ __device__ __forceinline__ int wrapi(int i, int n) { return i < 0 ? i + n : (i >
 
 __host__ __device__ __forceinline__ size_t lds_bytes_for(int cap)
 {
-    return (size_t)cap * (sizeof(double2) + sizeof(double) + 2 * sizeof(int32_t) + 1) + sizeof(Scratch) + 64;
+    return (size_t)cap * (sizeof(double2) + 2 * sizeof(double) + 3 * sizeof(int32_t)) + sizeof(Scratch) + 64;
 }
 
 __device__ __forceinline__ void carve_lds(Ctx &c, void *smem, int cap)
@@ -65,43 +82,52 @@ __device__ __forceinline__ void carve_lds(Ctx &c, void *smem, int cap)
     // cap is a multiple of 16, so every array stays 16-byte aligned
     c.xy = (double2 *)smem;
     c.key = (double *)(c.xy + cap);
-    c.stamp = (int32_t *)(c.key + cap);
+    c.ang_ord = c.key + cap;
+    c.stamp = (int32_t *)(c.ang_ord + cap);
     c.id = c.stamp + cap;
-    c.sc = (Scratch *)(c.id + cap);
-    c.flag = (uint8_t *)(c.sc + 1);
+    c.list = c.id + cap;
+    c.sc = (Scratch *)(c.list + cap);
 }
 
 // ------------------------------------------------------------------------------------------ load / store
 
-__device__ __forceinline__ void load_keys(Ctx &c, const DevState &S)
+__device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env)
 {
-    if (c.keys_loaded) return;
-    for (int i = c.lane; i < c.n; i += 64) {
-        c.key[i] = S.ring_key[c.off + i];
-        c.stamp[i] = S.ring_stamp[c.off + i];
-    }
-    c.keys_loaded = true;
-    __syncthreads();
-}
-
-__device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env, bool with_keys)
-{
-    c.lane = lane_id();
+    const int lane = lane_id();
+    c.lane = lane;
     c.env = env;
-    c.off = S.env_off[env];
-    c.n0 = S.env_off[env + 1] - c.off;
+    c.base = (size_t)env * S.cap;
+    // everything below is independent: one HBM round trip
     const EnvScalars s = S.scal[env];
-    c.n = s.n; c.ref = s.ref; c.n_elem = s.n_elem; c.failed = s.failed; c.n_new = s.n_new;
-    c.counter = s.counter; c.status = s.status; c.dom = s.dom; c.bl = s.bl; c.area = s.area;
-    c.keys_loaded = false;
-    c.ring_dirty = false;
-    for (int i = c.lane; i < c.n; i += 64) {
-        c.xy[i] = S.ring_xy[c.off + i];
-        c.id[i] = S.ring_id[c.off + i];
+    const int first = S.cap < 64 ? S.cap : 64;
+    double2 v_xy = make_double2(0, 0);
+    double v_key = 0;
+    int v_id = 0, v_st = kNotCand;
+    if (lane < first) {
+        v_xy = S.ring_xy[c.base + lane];
+        v_id = S.ring_id[c.base + lane];
+        v_key = S.ring_key[c.base + lane];
+        v_st = S.ring_stamp[c.base + lane];
     }
-    c.obs = c.lane < kObsDim ? S.obs_cache[(size_t)env * kObsDim + c.lane] : 0.0f;
+    c.obs = lane < kObsDim ? S.obs_cache[(size_t)env * kObsDim + lane] : 0.0f;
+    c.n = uniform_i32(s.n); c.ref = uniform_i32(s.ref); c.n_elem = uniform_i32(s.n_elem);
+    c.failed = uniform_i32(s.failed); c.n_new = uniform_i32(s.n_new); c.counter = uniform_i32(s.counter);
+    c.status = uniform_i32(s.status); c.dom = uniform_i32(s.dom);
+    c.bl = uniform_f64(s.bl); c.area = uniform_f64(s.area); c.ct = uniform_f64(s.ct); c.st = uniform_f64(s.st);
+    c.ring_dirty = false;
+    if (lane < first) {
+        c.xy[lane] = v_xy;
+        c.id[lane] = v_id;
+        c.key[lane] = v_key;
+        c.stamp[lane] = v_st;
+    }
+    for (int i = 64 + lane; i < c.n; i += 64) {
+        c.xy[i] = S.ring_xy[c.base + i];
+        c.id[i] = S.ring_id[c.base + i];
+        c.key[i] = S.ring_key[c.base + i];
+        c.stamp[i] = S.ring_stamp[c.base + i];
+    }
     __syncthreads();
-    if (with_keys) load_keys(c, S);
 }
 
 __device__ __forceinline__ void store_env(Ctx &c, const DevState &S)
@@ -109,10 +135,10 @@ __device__ __forceinline__ void store_env(Ctx &c, const DevState &S)
     __syncthreads();
     if (c.ring_dirty) {
         for (int i = c.lane; i < c.n; i += 64) {
-            S.ring_xy[c.off + i] = c.xy[i];
-            S.ring_id[c.off + i] = c.id[i];
-            S.ring_key[c.off + i] = c.key[i];
-            S.ring_stamp[c.off + i] = c.stamp[i];
+            S.ring_xy[c.base + i] = c.xy[i];
+            S.ring_id[c.base + i] = c.id[i];
+            S.ring_key[c.base + i] = c.key[i];
+            S.ring_stamp[c.base + i] = c.stamp[i];
         }
         if (c.lane < kObsDim) S.obs_cache[(size_t)c.env * kObsDim + c.lane] = c.obs;
     }
@@ -120,32 +146,17 @@ __device__ __forceinline__ void store_env(Ctx &c, const DevState &S)
         EnvScalars s;
         s.n = c.n; s.ref = c.ref; s.n_elem = c.n_elem; s.failed = c.failed; s.n_new = c.n_new;
         s.counter = c.counter; s.status = c.status; s.dom = c.dom; s.bl = c.bl; s.area = c.area;
-        s.pad[0] = 0; s.pad[1] = 0;
+        s.ct = c.ct; s.st = c.st;
         S.scal[c.env] = s;
     }
 }
 
 // ------------------------------------------------------------------------------------------ candidates (a5)
 
-// MeshGeneration.check_boundary_point, M:202-231.  Returns false for None.
-__device__ __forceinline__ bool check_boundary_point(const Ctx &c, const Params &p, int index, double &out)
-{
-    const int n = c.n;
-    const P2 v = ldp(c, index);
-    const double a0 = cw(v, ldp(c, wrapi(index + 1, n)), ldp(c, wrapi(index - 1, n)));
-    if (a0 >= p.max_ref_angle || a0 == 0.0) return false;
-    double sum_angle = 0.0;
-    sum_angle += a0 * p.w0;
-    const double a1 = cw(v, ldp(c, wrapi(index + 2, n)), ldp(c, wrapi(index - 2, n)));
-    sum_angle += a1 * p.w1;
-    out = sum_angle * (180.0 / kPi);  // math.degrees
-    return true;
-}
-
 // find_reference_point, M:269-290: head of the list ordered by (key asc, insertion desc)
 __device__ __forceinline__ int select_reference(const Ctx &c)
 {
-    double bk = __longlong_as_double(0x7ff0000000000000LL);  // +inf
+    double bk = kInf;
     int bs = kNotCand, bi = -1;
     for (int i = c.lane; i < c.n; i += 64) {
         const int st = c.stamp[i];
@@ -154,62 +165,246 @@ __device__ __forceinline__ int select_reference(const Ctx &c)
             if (k < bk || (k == bk && st > bs)) { bk = k; bs = st; bi = i; }
         }
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ok = shfl_xor_f64(bk, m);
-        const int os = __shfl_xor(bs, m, 64);
-        const int oi = __shfl_xor(bi, m, 64);
-        if (ok < bk || (ok == bk && os > bs)) { bk = ok; bs = os; bi = oi; }
+#define STEP(CTRL, MASK)                                                        \
+    {                                                                           \
+        const double ok = dpp_f64<CTRL, MASK>(kInf, bk);                        \
+        const int os = dpp_i32<CTRL, MASK>(kNotCand, bs);                       \
+        const int oi = dpp_i32<CTRL, MASK>(-1, bi);                             \
+        if (ok < bk || (ok == bk && os > bs)) { bk = ok; bs = os; bi = oi; }    \
     }
-    return bi;
+    MESHENV_DPP_REDUCE(STEP)
+#undef STEP
+    return lane_i32(bi, 63);
 }
 
-// ------------------------------------------------------------------------------------------ observation (a6)
+// the two angles of MeshGeneration.check_boundary_point (M:202-231) for ring slot `index`:
+// which = 0 -> cw(v; ring[index+1], ring[index-1]); which = 1 -> cw(v; ring[index+2], ring[index-2])
+__device__ __forceinline__ void key_angle_terms(const Ctx &c, int index, int which, double &cc, double &dd)
+{
+    const int n = c.n, o = which + 1;
+    cw_terms(ldp(c, index), ldp(c, wrapi(index + o, n)), ldp(c, wrapi(index - o, n)), cc, dd);
+}
+
+// key = degrees(0.618*a0 + 0.382*a1), None when a0 >= 0.972*pi or a0 == 0
+__device__ __forceinline__ bool key_from_angles(const Params &p, double a0, double a1, double &out)
+{
+    if (a0 >= p.max_ref_angle || a0 == 0.0) return false;
+    double sum_angle = 0.0;
+    sum_angle += a0 * p.w0;
+    sum_angle += a1 * p.w1;
+    out = sum_angle * (180.0 / kPi);  // math.degrees
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ observation (a6) + boundary quality
+
+// Boundary-quality request fused into find_next_state: the O(n) scan of compute_boundary_quality (M:329-382)
+// shares the observation scan's pass over the ring, its distances share stage A, its minimum shares the
+// reduction stage -- the two are independent chains, so the scheduler overlaps them.
+struct BqArgs {
+    int mode;    // 0 none (reset), 1 new vertex at ring slot a, 2 kept vertices at ring slots a, b (quad order)
+    int a, b;
+    double ang0, ang1;  // clockwise boundary angles (job lanes of the quad pass)
+    double q_ang0, q_ang2;  // quad corner angles 0 and 2; their sines are evaluated in stage B
+    double half01, half23;  // 0.5*e0*e1 and 0.5*e2*e3 of Mesh.compute_area (C:935-950)
+    double mesh_area;   // out; current_area is reduced by it before the observation is built (B:200)
+    double b_reward;    // out
+};
 
 // find_next_state, B:504-571 -> PointEnvironment.get_neighbors C:1073-1082 + get_radius_points C:1184-1282.
-// Needs keys in LDS.  Updates c.ref, c.bl, c.obs (lanes 0..17), c.status.
-__device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S)
+// Updates c.ref, c.bl, c.ct/st (action frame of the new state), c.obs (lanes 0..17), c.status; fills bq outputs.
+__device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArgs &bq)
 {
     const Params &p = S.prm;
     const int lane = c.lane, n = c.n;
     __syncthreads();
     const int idx = select_reference(c);
     c.ref = idx;
-    if (idx < 0) {  // the reference returns None here
-        c.status |= kStNoReference;
-        c.obs = 0.0f;
-        return;
-    }
-    c.status &= ~kStNoReference;
-    const int i_right = wrapi(idx - 1, n), i_left = wrapi(idx + 1, n);
-    const P2 ref = ldp(c, idx), right = ldp(c, i_right);
-    const double area_ratio = c.area / S.dom_const[c.dom].orig_area;
-
-    // base_length = round(sum of the 6 window edges / 6, 4): lane j holds edge j of the reference's
-    // summation order, the sum itself is sequential
-    double ed = 0.0;
-    if (lane < 6) ed = dist(ldp(c, wrapi(idx + 2 - lane, n)), ldp(c, wrapi(idx + 3 - lane, n)));
-    double sum = bcast_f64(ed, 0);
-#pragma unroll
-    for (int j = 1; j < 6; j++) sum += bcast_f64(ed, j);
-    const double bl = round4_py(sum / 6);
-    c.bl = bl;
+    MESHENV_STAMP(c, 9);
+    const bool none = idx < 0;  // the reference returns None here; the reward terms are still needed
+    const int idc = none ? 0 : idx;
+    const int i_right = wrapi(idc - 1, n), i_left = wrapi(idc + 1, n);
+    const double2 ref_v = c.xy[idc], right_v = c.xy[i_right];
+    const P2 ref = mkp(uniform_f64(ref_v.x), uniform_f64(ref_v.y));
+    const P2 right = mkp(uniform_f64(right_v.x), uniform_f64(right_v.y));
     const double radius = p.radius;
-    const double target_length = bl * radius;
 
-    // lanes 0..5: the six neighbour rows; lane 0 also yields rotation_angle, lane 3 yields theta
-    //   lane j < 3 : right side i = j     -> vertex idx-1-j
-    //   lane j >= 3: left side  i = j - 3 -> vertex idx+1+(j-3)
-    double nd = 0.0, na = 0.0;
-    if (lane < 6) {
-        const int vi = lane < 3 ? wrapi(idx - 1 - lane, n) : wrapi(idx + 1 + (lane - 3), n);
-        const P2 v = ldp(c, vi);
-        nd = (dist(ref, v) / radius) / bl;
-        na = lane == 0 ? cw(ref, right, mkp(ref.x + 1, ref.y)) : cw(ref, v, right);
+    // ---- stage A.  dist jobs: lanes 0..5 window edge j of base_length, lanes 8..14 boundary-quality
+    //      distances, lanes 16..21 reference->neighbour distances.  atan2 jobs: lanes 0..5 the six neighbour
+    //      rows (lane 0 -> rotation_angle, lane 3 -> theta), lane 6 the action frame (D:69).
+    //   neighbour lane j < 3 : right side i = j     -> vertex idx-1-j
+    //   neighbour lane j >= 3: left side  i = j - 3 -> vertex idx+1+(j-3)
+    int ia = 0, ib = 0;
+    bool dj = false;
+    if (lane < 6) { ia = wrapi(idc + 2 - lane, n); ib = wrapi(idc + 3 - lane, n); dj = true; }
+    else if (lane >= 16 && lane < 22) {
+        const int j = lane - 16;
+        ia = idc; ib = j < 3 ? wrapi(idc - 1 - j, n) : wrapi(idc + 1 + (j - 3), n); dj = true;
+    } else if (bq.mode == 1) {
+        if (lane == 8) { ia = bq.a; ib = wrapi(bq.a + 1, n); dj = true; }
+        else if (lane == 9) { ia = bq.a; ib = wrapi(bq.a - 1, n); dj = true; }
+        else if (lane >= 10 && lane < 14) { ia = wrapi(bq.a - 2 + (lane - 10), n); ib = wrapi(bq.a - 1 + (lane - 10), n); dj = true; }
+    } else if (bq.mode == 2) {
+        const int lo = bq.a < bq.b ? bq.a : bq.b;
+        if (lane == 8) { ia = bq.a; ib = bq.b; dj = true; }
+        else if (lane >= 10 && lane < 15) { ia = wrapi(lo - 2 + (lane - 10), n); ib = wrapi(lo - 1 + (lane - 10), n); dj = true; }
     }
-    const double rot = bcast_f64(na, 0);
-    const double theta = bcast_f64(na, 3);
-    const double clipmax = theta + kPi / 2;
+    double dv = 0.0;
+    if (dj) dv = dist(ldp(c, ia), ldp(c, ib));
+    double jy = 0.0, jx = 1.0;
+    if (lane < 6) {
+        const int vi = lane < 3 ? wrapi(idc - 1 - lane, n) : wrapi(idc + 1 + (lane - 3), n);
+        if (lane == 0) cw_terms(ref, right, mkp(ref.x + 1, ref.y), jy, jx);
+        else cw_terms(ref, ldp(c, vi), right, jy, jx);
+    } else if (lane == 6) {
+        jy = right.y - ref.y;
+        jx = right.x - ref.x;
+    }
+    double jt = 0.0;
+    if (lane < 7) jt = atan2_nc(jy, jx);
+    const double na = cw_finish(jt);
+    // base_length = round(sum of the 6 window edges / 6, 4), summed in the reference's order
+    double sum = lane_f64(dv, 0);
+    sum += lane_f64(dv, 1);
+    sum += lane_f64(dv, 2);
+    sum += lane_f64(dv, 3);
+    sum += lane_f64(dv, 4);
+    sum += lane_f64(dv, 5);
+    const double bl = uniform_f64(round4_py(sum / 6));
+    const double target_length = uniform_f64(bl * radius);
+    const double rot = lane_f64(na, 0);
+    const double theta = lane_f64(na, 3);
+    const double thd = 2 * kPi - lane_f64(jt, 6);
+    const double clipmax = uniform_f64(theta + kPi / 2);
+    // boundary-quality distances
+    const double bq_d0 = lane_f64(dv, 8), bq_d1 = lane_f64(dv, 9);
+    double bq_sum = lane_f64(dv, 10);
+    bq_sum += lane_f64(dv, 11);
+    bq_sum += lane_f64(dv, 12);
+    bq_sum += lane_f64(dv, 13);
+    const double bq_sum5 = bq_sum + lane_f64(dv, 14);
+    const double dst = uniform_f64(bq_d0 + bq_d1);  // mode 1: d(new, next) + d(new, prev)
+    const double ndraw = __hiloint2double(__shfl(__double2hiint(dv), (lane & 7) + 16, 64), __shfl(__double2loint(dv), (lane & 7) + 16, 64));
+    MESHENV_STAMP(c, 10);
+
+    // ---- stage B: sincos jobs: lane 0 theta/2, lane 1 rotation_angle, lane 2 action frame,
+    //      lanes 3, 4 the two quad corners of Mesh.compute_area
+    double sj = 0.0, cj = 1.0;
+    if (lane < 5) {
+        const double arg = lane == 0 ? theta / 2 : lane == 1 ? rot : lane == 2 ? thd : lane == 3 ? bq.q_ang0 : bq.q_ang2;
+        const SinCos sc = sincos_nc(arg);
+        sj = sc.s;
+        cj = sc.c;
+    }
+    if (bq.mode != 0) {
+        bq.mesh_area = uniform_f64(bq.half01 * lane_f64(sj, 3) + bq.half23 * lane_f64(sj, 4));
+        c.area -= bq.mesh_area;
+    }
+    const double area_ratio = c.area / S.dom[c.dom].orig_area;
+    // bisector segment ref -> p_s (Vertex.rotate about the origin, C:146-160)
+    const double px = target_length * lane_f64(cj, 0), py = target_length * lane_f64(sj, 0);
+    const double cr = lane_f64(cj, 1), sr = lane_f64(sj, 1);
+    const double qx = (0.0 + cr * px) - sr * py;
+    const double qy = (0.0 + sr * px) + cr * py;
+    const double ux = uniform_f64((ref.x + qx) - ref.x), uy = uniform_f64((ref.y + qy) - ref.y);  // u = p_s - ref
+    MESHENV_STAMP(c, 11);
+
+    // ---- stage C: O(n) scan, traversal order ord = 0..n-2 <-> ring index idx-1-ord (C:1239-1267), fused with the
+    //      near-vertex scan of compute_boundary_quality (ring index = base + lane)
+    const double third = uniform_f64(theta / 3);
+    const u64 kSlotInit = ((u64)0x3f800000u << 32) | 0x7fffffffu;  // (1.0f, no vertex)
+    u64 k0 = kSlotInit, k1 = kSlotInit, k2 = kSlotInit;
+    double rbest = 1.0;
+    int rord = 0x7fffffff;
+    double m_d = kInf;
+    int carry = 0;
+    const int bqi = bq.a;
+    const int w1 = wrapi(bqi + 1, n), w2 = wrapi(bqi + 2, n), w3 = wrapi(bqi - 1, n), w4 = wrapi(bqi - 2, n);
+    const P2 add_v = ldp(c, bq.mode == 1 ? bqi : 0);
+    for (int base = 0; base < n; base += 64) {
+        // (1) observation scan
+        const int ord = base + lane;
+        const bool in_range = ord < n - 1;
+        const int ii = wrapi(idc - 1 - (in_range ? ord : 0), n);
+        const P2 v = ldp(c, ii);
+        double cc = 0.0, dd = 1.0;
+        if (in_range) cw_terms(ref, v, right, cc, dd);
+        double t = 0.0;
+        if (in_range) t = atan2_nc(cc, dd);
+        const double angle = cw_finish(t);
+        if (in_range) c.ang_ord[ord] = angle;
+        // (2) boundary-quality scan (mode 1): added(i) = near(i) && !added(i-1), M:355-357
+        if (bq.mode == 1) {
+            const int i = base + lane;
+            bool near = false;
+            if (i < n && !(i == bqi || i == w1 || i == w2 || i == w3 || i == w4)) near = dist(add_v, ldp(c, i)) < dst;
+            const unsigned long long m = __ballot(near);
+            bool added = false;
+            if (near) {
+                const unsigned long long zeros_below = ~m & ((1ULL << lane) - 1ULL);
+                if (zeros_below != 0ULL) {
+                    const int pz = 63 - __clzll((long long)zeros_below);
+                    added = ((lane - pz - 1) & 1) == 0;
+                } else {
+                    added = (lane & 1) == carry;
+                }
+            }
+            if (added) {
+                const double d = seg_point_distance(ldp(c, wrapi(i + 1, n)), ldp(c, i), add_v);
+                m_d = d < m_d ? d : m_d;
+            }
+            carry = (int)((__ballot(added) >> 63) & 1ULL);
+        }
+        const bool live = in_range && ii != i_right && ii != i_left && angle != 0.0;
+        if (live) {
+            const double d = dist(ref, v);
+            const double kf = angle / third;
+            if (kf < 3.0 && d < target_length) {
+                const int k = (int)kf;
+                const float cnd = (float)((d / radius) / bl);
+                const u64 key = ((u64)__float_as_uint(cnd) << 32) | (unsigned)ord;  // ord increases per lane: '<' keeps the first
+                if (k == 0) k0 = key < k0 ? key : k0;
+                else if (k == 1) k1 = key < k1 ? key : k1;
+                else k2 = key < k2 ? key : k2;
+            }
+            // Segment(ref, p_s).intersection_vertex(Segment(ring[i], ring[i+1])), C:649-668
+            const P2 b = ldp(c, wrapi(ii + 1, n));
+            const double wx = b.x - v.x, wy = b.y - v.y;
+            double s = 0.0, h = 0.0;
+            bool have = true;
+            if (wy == 0.0) {
+                have = uy != 0.0;
+                s = (v.y - ref.y) / uy;
+                h = (ref.x - v.x + s * ux) / wx;
+            } else if (wx == 0.0) {
+                have = ux != 0.0;
+                s = (v.x - ref.x) / ux;
+                h = (ref.y - v.y + s * uy) / wy;
+            } else {
+                s = ((ref.x - v.x) / wx - (ref.y - v.y) / wy) / (uy / wy - ux / wx);
+                h = (ref.x - v.x + s * ux) / wx;
+            }
+            if (have && 0.0 < s && s < 1.0 && 0.0 < h && h < 1.0) {
+                const double val = (dist(ref, mkp(ref.x + s * ux, ref.y + s * uy)) / radius) / bl;
+                if (val < rbest) { rbest = val; rord = ord; }
+            }
+        }
+    }
+    MESHENV_STAMP(c, 12);
+    // ---- reductions: first-wins minima as packed (value bits, order) keys, one interleaved DPP scan
+    u64 rk = (u64)__double_as_longlong(rbest), mk = (u64)__double_as_longlong(m_d);
+    const u64 my_rk = rk;
+    wave_min5_u64(k0, k1, k2, rk, mk);
+    const unsigned ro = wave_min_u32(my_rk == rk ? (unsigned)rord : 0xffffffffu);  // earliest among equal hits
+    rbest = __longlong_as_double((long long)rk);
+    m_d = __longlong_as_double((long long)mk);
+    const float s0 = __uint_as_float((unsigned)(k0 >> 32)), s1 = __uint_as_float((unsigned)(k1 >> 32)), s2 = __uint_as_float((unsigned)(k2 >> 32));
+    const int o0 = (int)(unsigned)k0, o1 = (int)(unsigned)k1, o2 = (int)(unsigned)k2;
+    const bool use_hit = rbest < 1.0 && (float)rbest < s1;
+    MESHENV_STAMP(c, 13);
+    __syncthreads();
+
+    // ---- observation rows
     if (lane < 6) {
         const int row = lane < 3 ? lane : 8 - (lane - 3);
         float v1;
@@ -217,162 +412,186 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S)
         else if (lane == 3) v1 = (float)theta;
         else if (lane < 3) v1 = (float)(na < kPi ? na : fmax(na, 1.5 * kPi) - 2 * kPi);
         else v1 = (float)fmin(na, clipmax);
-        c.sc->robs[2 * row] = (float)nd;
+        c.sc->robs[2 * row] = (float)((ndraw / radius) / bl);
         c.sc->robs[2 * row + 1] = v1;
-    }
-
-    // bisector segment ref -> p_s (Vertex.rotate about the origin, C:146-160)
-    const double px = target_length * cos(theta / 2), py = target_length * sin(theta / 2);
-    const double cr = cos(rot), sr = sin(rot);
-    const double qx = (0.0 + cr * px) - sr * py;
-    const double qy = (0.0 + sr * px) + cr * py;
-    const double ux = (ref.x + qx) - ref.x, uy = (ref.y + qy) - ref.y;  // u = p_s - ref
-
-    // O(n) scan, traversal order ord = 0..n-2 <-> ring index idx-1-ord (C:1239-1267)
-    const double third = theta / 3;
-    float s0 = 1.0f, s1 = 1.0f, s2 = 1.0f;  // best normalised distance per fan slot
-    int o0 = 0x7fffffff, o1 = 0x7fffffff, o2 = 0x7fffffff;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    double rbest = 1.0;
-    int rord = 0x7fffffff;
-    for (int ord = lane; ord < n - 1; ord += 64) {
-        const int ii = wrapi(idx - 1 - ord, n);
-        if (ii == i_right || ii == i_left) continue;
-        const P2 v = ldp(c, ii);
-        const double d = dist(ref, v);
-        const double angle = cw(ref, v, right);
-        if (angle == 0.0) continue;
-        const double kf = angle / third;
-        if (kf < 3.0 && d < target_length) {
-            const int k = (int)kf;
-            const float cnd = (float)((d / radius) / bl);
-            if (k == 0) { if (cnd < s0) { s0 = cnd; o0 = ord; a0 = angle; } }
-            else if (k == 1) { if (cnd < s1) { s1 = cnd; o1 = ord; a1 = angle; } }
-            else { if (cnd < s2) { s2 = cnd; o2 = ord; a2 = angle; } }
+    } else if (lane >= 8 && lane < 11) {
+        // fan rows: slot winners, or the three vertices around the edge the bisector hits (C:1269-1279)
+        const int j = lane - 8;
+        const float sw = j == 0 ? s0 : (j == 1 ? s1 : s2);
+        const int ow = j == 0 ? o0 : (j == 1 ? o1 : o2);
+        float fd = 1.0f;
+        float fa = (float)fmin(((2 * j + 1) * theta) / 6, clipmax);  // default [1, clip((2j+1)*theta/6)]
+        if (use_hit) {
+            const int ov = (int)ro + 1 - j;  // ring[_i - 1 + j] in traversal order
+            fd = (float)((dist(ref, ldp(c, wrapi(idc - 1 - ov, n))) / radius) / bl);
+            fa = (float)c.ang_ord[ov];
+        } else if (sw < 1.0f) {
+            fd = sw;
+            fa = (float)fmin(c.ang_ord[ow], clipmax);
         }
-        // Segment(ref, p_s).intersection_vertex(Segment(ring[i], ring[i+1])), C:649-668
-        const P2 b = ldp(c, wrapi(ii + 1, n));
-        const double wx = b.x - v.x, wy = b.y - v.y;
-        double s, h;
-        if (wy == 0.0) {
-            if (uy == 0.0) continue;
-            s = (v.y - ref.y) / uy;
-            h = (ref.x - v.x + s * ux) / wx;
-        } else if (wx == 0.0) {
-            if (ux == 0.0) continue;
-            s = (v.x - ref.x) / ux;
-            h = (ref.y - v.y + s * uy) / wy;
+        c.sc->robs[6 + 2 * j] = fd;
+        c.sc->robs[7 + 2 * j] = fa;
+    }
+    // ---- boundary quality (M:329-382 / M:392-426)
+    if (bq.mode != 0) {
+        double amin = 1e300;
+        bool have = false;
+        if (bq.ang0 < kPi / 3) { amin = bq.ang0; have = true; }
+        if (bq.ang1 < kPi / 3) { amin = bq.ang1 < amin ? bq.ang1 : amin; have = true; }
+        const double q1 = have ? 3 * amin / kPi : 1.0;
+        if (bq.mode == 1) {
+            const double targt_len = dst / 2;
+            const double mean_dist = bq_sum / 4;
+            const double smoothness = (targt_len < mean_dist ? targt_len : mean_dist) / (targt_len > mean_dist ? targt_len : mean_dist);
+            double q2 = 1.0;
+            if (m_d < 1e299) q2 = (m_d < 0.5 * dst) ? m_d / (0.5 * dst) : 1.0;
+            bq.b_reward = cbrt(smoothness * q1 * q2);  // math.pow(x, 1/3)
         } else {
-            s = ((ref.x - v.x) / wx - (ref.y - v.y) / wy) / (uy / wy - ux / wx);
-            h = (ref.x - v.x + s * ux) / wx;
+            const double targt_len = bq_d0;
+            const double mean_dist = bq_sum5 / 5;
+            const double smoothness = (targt_len < mean_dist ? targt_len : mean_dist) / (targt_len > mean_dist ? targt_len : mean_dist);
+            bq.b_reward = sqrt(q1 * smoothness);  // math.pow(angle_quality * smoothness, 1/2)
         }
-        if (0.0 < s && s < 1.0 && 0.0 < h && h < 1.0) {
-            const double val = (dist(ref, mkp(ref.x + s * ux, ref.y + s * uy)) / radius) / bl;
-            if (val < rbest) { rbest = val; rord = ord; }
-        }
-    }
-    // first-wins reductions
-    float w0 = s0, w1 = s1, w2 = s2;
-    int wo0 = o0, wo1 = o1, wo2 = o2;
-    wave_argmin_f32(w0, wo0);
-    wave_argmin_f32(w1, wo1);
-    wave_argmin_f32(w2, wo2);
-    double rb = rbest;
-    int ro = rord;
-    wave_argmin_f64(rb, ro);
-    // defaults of the fan rows: [1, clip((2j+1)*theta/6)]
-    float f0d = 1.0f, f1d = 1.0f, f2d = 1.0f;
-    float f0a = (float)fmin((1 * theta) / 6, clipmax);
-    float f1a = (float)fmin((3 * theta) / 6, clipmax);
-    float f2a = (float)fmin((5 * theta) / 6, clipmax);
-    if (w0 < 1.0f) { f0d = w0; f0a = (float)fmin(bcast_f64(a0, wo0 & 63), clipmax); }
-    if (w1 < 1.0f) { f1d = w1; f1a = (float)fmin(bcast_f64(a1, wo1 & 63), clipmax); }
-    if (w2 < 1.0f) { f2d = w2; f2a = (float)fmin(bcast_f64(a2, wo2 & 63), clipmax); }
-    if (rb < 1.0 && (float)rb < f1d) {
-        // the bisector hits edge (_i, _i+1) closer than the middle fan slot: report ring[_i-1.._i+1]
-        const int hit = idx - 1 - ro;  // the reference's loop variable (may be negative)
-        double hd = 0.0, ha = 0.0;
-        if (lane < 3) {
-            const P2 v = ldp(c, wrapi(wrapi(hit, n) + lane - 1, n));
-            hd = (dist(ref, v) / radius) / bl;
-            ha = cw(ref, v, right);
-        }
-        f0d = (float)bcast_f64(hd, 0); f0a = (float)bcast_f64(ha, 0);
-        f1d = (float)bcast_f64(hd, 1); f1a = (float)bcast_f64(ha, 1);
-        f2d = (float)bcast_f64(hd, 2); f2a = (float)bcast_f64(ha, 2);
-    }
-    if (lane == 0) {
-        float *r = c.sc->robs;
-        r[6] = f0d; r[7] = f0a; r[8] = f1d; r[9] = f1a; r[10] = f2d; r[11] = f2a;
     }
     __syncthreads();
-    if (lane < kObsDim) c.obs = round4_npf(c.sc->robs[lane]);
+    if (none) {
+        c.status |= kStNoReference;
+        c.obs = 0.0f;
+    } else {
+        c.status &= ~kStNoReference;
+        c.bl = bl;
+        c.ct = lane_f64(cj, 2);
+        c.st = lane_f64(sj, 2);
+        if (lane < kObsDim) c.obs = round4_npf(c.sc->robs[lane]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ point in polygon (a7)
 
-__device__ __forceinline__ double round4_by(bool is_np, double v) { return is_np ? round4_np(v) : round4_py(v); }
-
 // is_point_inside_area -> calculate_crossing_segments, M:539-546, 47-102.  One ring edge per lane.
+// Orientation tests only use sign and zero-ness of round(dy, 4), so the scaled roundings are used.
 __device__ __forceinline__ bool point_inside(const Ctx &c, const Params &prm, P2 p)
 {
-    const int n = c.n, n0 = c.n0;
+    const int n = c.n;
     const P2 far = mkp(prm.ray_length, p.y);
-    int count = 0;
-    for (int i = c.lane; i < n; i += 64) {
-        const int im1 = wrapi(i - 1, n);
-        const P2 vi = ldp(c, i), vm = ldp(c, im1);
-        const bool np_i = c.id[i] >= n0, np_m = c.id[im1] >= n0;
-        const double orientation = round4_by(np_i || np_m, vi.y - vm.y);
-        if (orientation == 0.0) continue;
-        // is_cross is a pure conjunction; the ray-side test is the selective one, so it goes first
-        if (!(straddle(p, far, vi, vm) && straddle(vi, vm, p, far))) continue;
-        if (round4_np(vi.y - p.y) == 0.0) {
-            const int ip1 = wrapi(i + 1, n);
-            const double next_o = round4_by(c.id[ip1] >= n0 || np_i, ldp(c, ip1).y - vi.y);
-            if (next_o == 0.0) continue;
-            if (next_o * orientation < 0.0) continue;
-            if (orientation < 0.0) count += 1;
-        } else if (round4_np(vm.y - p.y) == 0.0) {
-            const int im2 = wrapi(i - 2, n);
-            const double pre_o = round4_by(np_m || c.id[im2] >= n0, vm.y - ldp(c, im2).y);
-            if (pre_o == 0.0) continue;
-            if (pre_o * orientation < 0.0) continue;
-            if (orientation < 0.0) continue;
-            count += 1;
+    int parity = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + c.lane;
+        bool counted = false;
+        if (i < n) {
+            const int im1 = wrapi(i - 1, n);
+            const P2 vi = ldp(c, i), vm = ldp(c, im1);
+            const bool np_i = (c.id[i] & kNewBit) != 0, np_m = (c.id[im1] & kNewBit) != 0;
+            const double dy = vi.y - vm.y;
+            const double orientation = (np_i || np_m) ? round4_np_scaled(dy) : round4_py_scaled(dy);
+            // is_cross is a pure conjunction; the ray-side test is the selective one, so it goes first
+            if (orientation != 0.0 && straddle(p, far, vi, vm) && straddle(vi, vm, p, far)) {
+                if (round4_np_scaled(vi.y - p.y) == 0.0) {
+                    const int ip1 = wrapi(i + 1, n);
+                    const double dyn = ldp(c, ip1).y - vi.y;
+                    const double next_o = ((c.id[ip1] & kNewBit) != 0 || np_i) ? round4_np_scaled(dyn) : round4_py_scaled(dyn);
+                    counted = next_o != 0.0 && !(next_o * orientation < 0.0) && orientation < 0.0;
+                } else if (round4_np_scaled(vm.y - p.y) == 0.0) {
+                    const int im2 = wrapi(i - 2, n);
+                    const double dyp = vm.y - ldp(c, im2).y;
+                    const double pre_o = (np_m || (c.id[im2] & kNewBit) != 0) ? round4_np_scaled(dyp) : round4_py_scaled(dyp);
+                    counted = pre_o != 0.0 && !(pre_o * orientation < 0.0) && !(orientation < 0.0);
+                } else {
+                    counted = true;
+                }
+            }
+        }
+        parity ^= __popcll(__ballot(counted)) & 1;
+    }
+    return parity != 0;
+}
+
+// ------------------------------------------------------------------------------------------ quad pass (a9 + speculative a5/a12 jobs)
+
+// Description of the ring AFTER the extraction, addressed without touching LDS (the quad may still be
+// rejected): new-vertex rule: slot `lo` holds new_point, everything else unchanged; removal rules: slots
+// lo < hi are deleted and the ring is compacted.
+struct VRing {
+    int n;        // length after the update
+    int lo, hi;   // removal: deleted slots (old indices); new vertex: lo = slot of the new vertex, hi = -1
+    bool is_new;
+    P2 new_point;
+};
+
+__device__ __forceinline__ P2 vr_at(const Ctx &c, const VRing &r, int j)
+{
+    if (r.is_new) return j == r.lo ? r.new_point : ldp(c, j);
+    int o = j + (j >= r.lo ? 1 : 0);
+    o += (o >= r.hi ? 1 : 0);
+    return ldp(c, o);
+}
+
+// Mesh.is_valid(0), C:730-749 + segments_crossed C:806-818, plus every other evaluation that only depends on
+// the quad and the post-update ring, batched so that a valid extraction pays ONE atan2 stage here:
+//   straddle jobs  lanes 0..3   the four Segment.straddle calls of segments_crossed
+//   dist jobs      lanes 0..5   quad edges e0..e3 and diagonals d02, d13 (reward)         -> tmp2[0..5]
+//   atan2 jobs     lanes 0..3   quad corner angles                                       -> ang[0..3]
+//                  lanes 4..11  the two key angles of the four ref_neighbors (M:202-231) -> tmp[0..7]
+//                  lanes 12,13  boundary-quality angles (M:333-340 / M:400-407)          -> tmp[8..9]
+// pk = packed ring slots of ref_neighbors (4 x 16 bit... passed as four ints), bc0/bc1 = centres of the
+// boundary-quality angles on the post-update ring.
+__device__ __forceinline__ bool quad_pass(Ctx &c, const Params &prm, const VRing &vr, int p0, int p1, int p2, int p3,
+                                          int bc0, int bc1)
+{
+    const int lane = c.lane;
+    const double2 *q = c.sc->q;
+    // (a) segments_crossed: is_cross(m0m1, m2m3) || is_cross(m0m3, m1m2); 4 independent straddles
+    bool sres = false;
+    if (lane < 4) {
+        // lane:        0        1        2        3
+        // self    (m0,m1)  (m2,m3)  (m0,m3)  (m1,m2)
+        // other   (m2,m3)  (m0,m1)  (m1,m2)  (m0,m3)
+        const int a = (0x1020 >> (4 * lane)) & 3, b = (0x2331 >> (4 * lane)) & 3;
+        const int cc = (0x0102 >> (4 * lane)) & 3, d = (0x3213 >> (4 * lane)) & 3;
+        sres = straddle(mkp(q[a].x, q[a].y), mkp(q[b].x, q[b].y), mkp(q[cc].x, q[cc].y), mkp(q[d].x, q[d].y));
+    }
+    const unsigned sm = (unsigned)__ballot(sres);
+    if (((sm & 3u) == 3u) || ((sm & 12u) == 12u)) return false;
+    // (b) reward distances
+    if (lane < 6) {
+        // e0=(0,3) e1=(1,0) e2=(2,1) e3=(3,2) d02=(0,2) d13=(1,3)
+        const int a = (0x103210 >> (4 * lane)) & 3, b = (0x322103 >> (4 * lane)) & 3;
+        c.sc->tmp2[lane] = dist(mkp(q[a].x, q[a].y), mkp(q[b].x, q[b].y));
+    }
+    // (c) atan2 jobs
+    double jy = 0.0, jx = 1.0;
+    if (lane < 4) {
+        const double2 a = q[lane], b = q[(lane + 1) & 3], d = q[(lane + 3) & 3];
+        cw_terms(mkp(a.x, a.y), mkp(b.x, b.y), mkp(d.x, d.y), jy, jx);
+    } else if (lane < 12) {
+        const int k = (lane - 4) >> 1, o = ((lane - 4) & 1) + 1;
+        const int pos = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+        cw_terms(vr_at(c, vr, pos), vr_at(c, vr, wrapi(pos + o, vr.n)), vr_at(c, vr, wrapi(pos - o, vr.n)), jy, jx);
+    } else if (lane < 14) {
+        const int ctr = lane == 12 ? bc0 : bc1;
+        cw_terms(vr_at(c, vr, ctr), vr_at(c, vr, wrapi(ctr + 1, vr.n)), vr_at(c, vr, wrapi(ctr - 1, vr.n)), jy, jx);
+    }
+    bool bad = false;
+    if (lane < 14) {
+        const double a = cw_finish(atan2_nc(jy, jx));
+        if (lane < 4) {
+            c.sc->ang[lane] = a;
+            bad = a > prm.max_degree || a < prm.min_degree;
         } else {
-            count += 1;
+            c.sc->tmp[lane - 4] = a;
         }
     }
-    return (wave_sum_i32(count) & 1) != 0;
-}
-
-// ------------------------------------------------------------------------------------------ quad validity (a9, a10)
-
-// Mesh.is_valid(0), C:730-749 + segments_crossed C:806-818.  Quad in c.sc->q; corner angles land in c.sc->ang.
-__device__ __forceinline__ bool quad_is_valid(Ctx &c, const Params &prm)
-{
-    const double2 *q = c.sc->q;
-    const P2 m0 = mkp(q[0].x, q[0].y), m1 = mkp(q[1].x, q[1].y), m2 = mkp(q[2].x, q[2].y), m3 = mkp(q[3].x, q[3].y);
-    bool bad = false;
-    double deg = 0.0;
-    if (c.lane < 4) {
-        const double2 a = q[c.lane], b = q[(c.lane + 1) & 3], d = q[(c.lane + 3) & 3];
-        deg = cw(mkp(a.x, a.y), mkp(b.x, b.y), mkp(d.x, d.y));
-        c.sc->ang[c.lane] = deg;
-        bad = deg > prm.max_degree || deg < prm.min_degree;
-    }
-    const bool crossed = is_cross(m0, m1, m2, m3) || is_cross(m0, m3, m1, m2);
     const bool any_bad = __ballot(bad) != 0ULL;
     __syncthreads();
-    return !crossed && !any_bad;
+    return !any_bad;
 }
 
-// check_intersection_with_boundary, M:510-530.  mpos[k] = ring slot of quad vertex k (-1 = new vertex),
-// r = position of the reference vertex in the quad.  One ring vertex per lane.
-__device__ __forceinline__ bool intersects_boundary(const Ctx &c, int mp0, int mp1, int mp2, int mp3, int r)
+// check_intersection_with_boundary, M:510-530.  mp* = ring slots of the quad vertices (-1 = new vertex),
+// r = position of the reference vertex in the quad.  Pass 1: one ring vertex per lane, distance filter,
+// survivors compacted into an LDS list.  Pass 2: one (vertex, quad edge, ring neighbour) test per lane.
+__device__ __forceinline__ bool intersects_boundary(Ctx &c, int mp0, int mp1, int mp2, int mp3, int r)
 {
-    const int n = c.n;
+    const int n = c.n, lane = c.lane;
     const double2 *q = c.sc->q;
     const P2 ref = mkp(q[r].x, q[r].y);
     double max_dist = -1.0;
@@ -383,111 +602,37 @@ __device__ __forceinline__ bool intersects_boundary(const Ctx &c, int mp0, int m
             max_dist = d > max_dist ? d : max_dist;
         }
     }
+    int count = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        bool near = false;
+        if (i < n && !(i == mp0 || i == mp1 || i == mp2 || i == mp3)) near = dist(ref, ldp(c, i)) < max_dist;
+        const unsigned long long m = __ballot(near);
+        if (near) c.list[count + __popcll(m & ((1ULL << lane) - 1ULL))] = i;
+        count += __popcll(m);
+    }
+    if (count == 0) return false;
+    __syncthreads();
     const double2 qa = q[(r + 3) & 3], qb = q[(r + 2) & 3], qc = q[(r + 1) & 3];
     const P2 c0a = mkp(qa.x, qa.y), c0b = mkp(qb.x, qb.y);  // (m[r-1], m[r-2])
-    const P2 c1a = c0b, c1b = mkp(qc.x, qc.y);              // (m[r-2], m[r-3])
-    bool hit = false;
-    for (int i = c.lane; i < n; i += 64) {
-        if (i == mp0 || i == mp1 || i == mp2 || i == mp3) continue;
-        const P2 v = ldp(c, i);
-        if (!(dist(ref, v) < max_dist)) continue;
-        const int ip = wrapi(i - 1, n), in = wrapi(i + 1, n);
-        const bool use_p = !(ip == mp0 || ip == mp1 || ip == mp2 || ip == mp3);
-        const bool use_n = !(in == mp0 || in == mp1 || in == mp2 || in == mp3);
-        const P2 vp = ldp(c, ip), vn = ldp(c, in);
-        if (use_p && (is_cross(c0a, c0b, v, vp) || is_cross(c1a, c1b, v, vp))) hit = true;
-        if (!hit && use_n && (is_cross(c0a, c0b, v, vn) || is_cross(c1a, c1b, v, vn))) hit = true;
-    }
-    return __ballot(hit) != 0ULL;
-}
-
-// ------------------------------------------------------------------------------------------ reward (a12)
-
-// compute_boundary_quality(add_v), M:329-382; index = ring slot of the new vertex
-__device__ __forceinline__ double boundary_quality_new(Ctx &c, int index)
-{
-    const int n = c.n, lane = c.lane;
-    const P2 add_v = ldp(c, index);
-    const int w1 = wrapi(index + 1, n), w2 = wrapi(index + 2, n), w3 = wrapi(index - 1, n), w4 = wrapi(index - 2, n);
-    // angles at the two ring neighbours of the new vertex (lanes 0, 1)
-    double ang = 0.0;
-    if (lane < 2) {
-        const int ctr = lane == 0 ? w1 : w3;
-        ang = cw(ldp(c, ctr), ldp(c, wrapi(ctr + 1, n)), ldp(c, wrapi(ctr - 1, n)));
-    }
-    const double ang0 = bcast_f64(ang, 0), ang1 = bcast_f64(ang, 1);
-    double amin = 1e300;
-    bool have = false;
-    if (ang0 < kPi / 3) { amin = ang0; have = true; }
-    if (ang1 < kPi / 3) { amin = ang1 < amin ? ang1 : amin; have = true; }
-    const double q1 = have ? 3 * amin / kPi : 1.0;
-
-    const double dst = dist(add_v, ldp(c, w1)) + dist(add_v, ldp(c, w3));
-    // close_vs: vertices outside the 5-window nearer than dst; a vertex is skipped when its predecessor
-    // index was appended (M:355-357)  ->  added(i) = near(i) && !added(i-1)
-    double m_d = 1e300;
-    int carry = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        bool near = false;
-        if (i < n && !(i == index || i == w1 || i == w2 || i == w3 || i == w4)) near = dist(add_v, ldp(c, i)) < dst;
-        const unsigned long long m = __ballot(near);
-        bool added = false;
-        if (near) {
-            const unsigned long long zeros_below = ~m & ((1ULL << lane) - 1ULL);
-            if (zeros_below != 0ULL) {
-                const int pz = 63 - __clzll((long long)zeros_below);
-                added = ((lane - pz - 1) & 1) == 0;
-            } else {
-                added = (lane & 1) == carry;
+    const P2 c1b = mkp(qc.x, qc.y);                          // (m[r-2], m[r-3])
+    bool any_hit = false;
+    const int total = 4 * count;
+    for (int j0 = 0; j0 < total && !any_hit; j0 += 64) {
+        const int j = j0 + lane;
+        bool hit = false;
+        if (j < total) {
+            const int i = c.list[j >> 2];
+            const int nb = (j & 2) ? wrapi(i + 1, n) : wrapi(i - 1, n);
+            if (!(nb == mp0 || nb == mp1 || nb == mp2 || nb == mp3)) {
+                const P2 ea = (j & 1) ? c0b : c0a, eb = (j & 1) ? c1b : c0b;
+                hit = is_cross(ea, eb, ldp(c, i), ldp(c, nb));
             }
         }
-        if (added) {
-            const double d = seg_point_distance(ldp(c, wrapi(i + 1, n)), ldp(c, i), add_v);
-            m_d = d < m_d ? d : m_d;
-        }
-        carry = (int)((__ballot(added) >> 63) & 1ULL);
+        any_hit = __ballot(hit) != 0ULL;
     }
-    m_d = wave_min_f64(m_d);
-    const double targt_len = dst / 2;
-    double ed = 0.0;
-    if (lane < 4) ed = dist(ldp(c, wrapi(index - 2 + lane, n)), ldp(c, wrapi(index - 1 + lane, n)));
-    double sum = bcast_f64(ed, 0);
-    sum += bcast_f64(ed, 1);
-    sum += bcast_f64(ed, 2);
-    sum += bcast_f64(ed, 3);
-    const double mean_dist = sum / 4;
-    const double smoothness = (targt_len < mean_dist ? targt_len : mean_dist) / (targt_len > mean_dist ? targt_len : mean_dist);
-    double q2 = 1.0;
-    if (m_d < 1e299) q2 = (m_d < 0.5 * dst) ? m_d / (0.5 * dst) : 1.0;
-    return cbrt(smoothness * q1 * q2);  // math.pow(x, 1/3)
-}
-
-// compute_ele_boundary_quality else-branch, M:392-426; t0/t1 = ring slots of the kept quad vertices in quad order
-__device__ __forceinline__ double boundary_quality_kept(Ctx &c, int t0, int t1)
-{
-    const int n = c.n, lane = c.lane;
-    double ang = 0.0;
-    if (lane < 2) {
-        const int ctr = lane == 0 ? t0 : t1;
-        ang = cw(ldp(c, ctr), ldp(c, wrapi(ctr + 1, n)), ldp(c, wrapi(ctr - 1, n)));
-    }
-    const double ang0 = bcast_f64(ang, 0), ang1 = bcast_f64(ang, 1);
-    double amin = 1e300;
-    bool have = false;
-    if (ang0 < kPi / 3) { amin = ang0; have = true; }
-    if (ang1 < kPi / 3) { amin = ang1 < amin ? ang1 : amin; have = true; }
-    const int index = t0 < t1 ? t0 : t1;
-    const double targt_len = dist(ldp(c, t0), ldp(c, t1));
-    double ed = 0.0;
-    if (lane < 5) ed = dist(ldp(c, wrapi(index - 2 + lane, n)), ldp(c, wrapi(index - 1 + lane, n)));
-    double sum = bcast_f64(ed, 0);
-#pragma unroll
-    for (int j = 1; j < 5; j++) sum += bcast_f64(ed, j);
-    const double mean_dist = sum / 5;
-    const double smoothness = (targt_len < mean_dist ? targt_len : mean_dist) / (targt_len > mean_dist ? targt_len : mean_dist);
-    const double angle_quality = have ? 3 * amin / kPi : 1.0;
-    return sqrt(angle_quality * smoothness);  // math.pow(x, 1/2)
+    __syncthreads();
+    return any_hit;
 }
 
 // ------------------------------------------------------------------------------------------ episode control
@@ -495,22 +640,24 @@ __device__ __forceinline__ double boundary_quality_kept(Ctx &c, int t0, int t1)
 // reset(): copy the domain's precomputed reset state (B:67-84 computes only per-domain constants)
 __device__ __forceinline__ void reset_from_domain(Ctx &c, const DevState &S)
 {
-    const int doff = S.dom_off[c.dom];
+    const DomConst dc = S.dom[c.dom];
+    const int doff = uniform_i32(dc.off), n0 = uniform_i32(dc.n0);
     __syncthreads();
-    for (int i = c.lane; i < c.n0; i += 64) {
+    for (int i = c.lane; i < n0; i += 64) {
         c.xy[i] = S.dom_xy[doff + i];
         c.id[i] = i;
         c.key[i] = S.dom_key[doff + i];
         c.stamp[i] = S.dom_stamp[doff + i];
     }
-    c.n = c.n0;
-    c.ref = S.dom_ref[c.dom];
-    c.bl = S.dom_bl[c.dom];
-    c.area = S.dom_const[c.dom].orig_area;
+    c.n = n0;
+    c.ref = uniform_i32(dc.ref);
+    c.bl = uniform_f64(dc.bl);
+    c.ct = uniform_f64(dc.ct);
+    c.st = uniform_f64(dc.st);
+    c.area = uniform_f64(dc.orig_area);
     c.n_elem = 0; c.failed = 0; c.n_new = 0; c.counter = 0;
     c.status = c.ref < 0 ? kStNoReference : 0;
     c.obs = c.lane < kObsDim ? S.dom_obs[(size_t)c.dom * kObsDim + c.lane] : 0.0f;
-    c.keys_loaded = true;
     c.ring_dirty = true;
     __syncthreads();
 }
@@ -543,12 +690,11 @@ __device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float 
     StepResult out;
     out.valid = false;
     int done = 0;
-    bool failed = true;
+    bool failed = true, no_reference = false;
     double reward = 0.0;
     const int index = c.ref;
     const int n = c.n;
 
-    bool no_reference = false;
     if (index < 0) {
         // no reference vertex (the reference's find_next_state returned None and its next step() would
         // raise): end the episode as truncated
@@ -567,25 +713,28 @@ __device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float 
         else if (a0 >= 0.5f) rule = 1;
         else {
             rule = 0;
-            // action_2_point -> detransformation, B:616-625, B:98-106, D:67-83
+            // action_2_point -> detransformation, B:616-625, B:98-106, D:67-83; cos/sin of the frame angle are
+            // per-state values computed with the observation
             const double px = (double)round4_npf(a1), py = (double)round4_npf(a2);
-            const P2 p0 = ldp(c, index), p1 = ldp(c, wrapi(index - 1, n));
-            const double theta = 2 * kPi - atan2(p1.y - p0.y, p1.x - p0.x);
-            const double ct = cos(theta), st = sin(theta);
-            double ox = ct * px + st * py;
-            double oy = -st * px + ct * py;
+            const P2 p0 = ldp(c, index);
+            double ox = c.ct * px + c.st * py;
+            double oy = -c.st * px + c.ct * py;
             ox *= c.bl;
             oy *= c.bl;
             ox += p0.x;
             oy += p0.y;
-            new_point = mkp(round4_np(ox), round4_np(oy));
-            if (point_inside(c, prm, new_point)) {
+            new_point = mkp(uniform_f64(round4_np(ox)), uniform_f64(round4_np(oy)));
+            MESHENV_STAMP(c, 1);
+            const bool inside = point_inside(c, prm, new_point);
+            MESHENV_STAMP(c, 2);
+            if (inside) {
                 // find_same_point, B:599-602: first ring vertex within eps
-                int first = 0x7fffffff;
-                for (int i = lane; i < n; i += 64)
-                    if (i < first && dist(ldp(c, i), new_point) < prm.same_eps) first = i;
-                first = wave_min_i32(first);
-                if (first != 0x7fffffff) rule = -1;  // existing point: the rule -1 quad, B:168-175
+                bool same = false;
+                for (int i0 = 0; i0 < n && !same; i0 += 64) {
+                    const int i = i0 + lane;
+                    same = __ballot(i < n && dist(ldp(c, i), new_point) < prm.same_eps) != 0ULL;
+                }
+                if (same) rule = -1;  // existing point: the rule -1 quad, B:168-175
                 else new_vertex = true;
             } else {
                 reward += c.n_elem ? -1.0 / c.n_elem : -1.0;
@@ -600,58 +749,91 @@ __device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float 
             } else {  // [i-2, i-1, i, i+1], B:156-162
                 mp0 = wrapi(index - 2, n); mp1 = wrapi(index - 1, n); mp2 = index; mp3 = wrapi(index + 1, n); r = 2;
             }
+            // the ring as update_boundary (M:575-648) would leave it, and the slots it touches
+            VRing vr;
+            vr.is_new = new_vertex;
+            vr.new_point = new_point;
+            int p0, p1, p2, p3;  // ref_neighbors as post-update ring slots
+            int t0 = 0, t1 = 0;  // post-update slots of the kept quad vertices
+            int bc0, bc1;
+            if (new_vertex) {
+                vr.n = n; vr.lo = index; vr.hi = -1;
+                p0 = wrapi(index + 1, n); p1 = wrapi(index - 1, n); p2 = wrapi(index + 2, n); p3 = wrapi(index - 2, n);
+                bc0 = wrapi(index + 1, n); bc1 = wrapi(index - 1, n);
+            } else {
+                vr.lo = mp1 < mp2 ? mp1 : mp2; vr.hi = mp1 < mp2 ? mp2 : mp1; vr.n = n - 2;
+                t0 = mp0 - (mp0 > vr.lo ? 1 : 0) - (mp0 > vr.hi ? 1 : 0);
+                t1 = mp3 - (mp3 > vr.lo ? 1 : 0) - (mp3 > vr.hi ? 1 : 0);
+                const int id = t0 > t1 ? t0 : t1, nn = n - 2;
+                p0 = wrapi(id, nn); p1 = wrapi(id - 1, nn); p2 = wrapi(id + 1, nn); p3 = wrapi(id - 2, nn);
+                bc0 = t0; bc1 = t1;
+            }
             __syncthreads();
             if (lane < 4) {
                 const int mp = lane == 0 ? mp0 : lane == 1 ? mp1 : lane == 2 ? mp2 : mp3;
                 c.sc->q[lane] = mp < 0 ? make_double2(new_point.x, new_point.y) : c.xy[mp];
             }
             __syncthreads();
-            bool ok = quad_is_valid(c, prm);
+            MESHENV_STAMP(c, 3);
+            bool ok = quad_pass(c, prm, vr, p0, p1, p2, p3, bc0, bc1);
+            MESHENV_STAMP(c, 4);
             if (ok) ok = !intersects_boundary(c, mp0, mp1, mp2, mp3, r);
+            MESHENV_STAMP(c, 5);
             if (ok) {
-                load_keys(c, S);
-                const int g0 = mp0 < 0 ? c.n0 + c.n_new : c.id[mp0];
+                const int g0 = mp0 < 0 ? (kNewBit | c.n_new) : c.id[mp0];
                 const int g1 = c.id[mp1], g2 = c.id[mp2], g3 = c.id[mp3];
                 log_quad(c, S, g0, g1, g2, g3);  // generated_meshes.append, B:192
 
-                // quad geometry for the reward, from the pre-update coordinates (Mesh holds the Vertex objects)
-                const double2 *q = c.sc->q;
-                const P2 m0 = mkp(q[0].x, q[0].y), m1 = mkp(q[1].x, q[1].y), m2 = mkp(q[2].x, q[2].y), m3 = mkp(q[3].x, q[3].y);
-                const double e0 = dist(m0, m3), e1 = dist(m1, m0), e2 = dist(m2, m1), e3 = dist(m3, m2);
-                const double ang0 = c.sc->ang[0], ang1 = c.sc->ang[1], ang2 = c.sc->ang[2], ang3 = c.sc->ang[3];
-                // Mesh.compute_area, C:935-950: corner_1 == corner angle 0, corner_3 == corner angle 2
-                const double mesh_area = 0.5 * e0 * e1 * sin(ang0) + 0.5 * e2 * e3 * sin(ang2);
-                // Mesh.get_quality('robust'), C:873-884
-                double mn = e1 < e0 ? e1 : e0;
-                mn = e2 < mn ? e2 : mn;
-                mn = e3 < mn ? e3 : mn;
-                const double d02 = dist(m0, m2), d13 = dist(m1, m3);
-                const double q1 = sqrt(2.0) * mn / (d13 > d02 ? d13 : d02);
-                double amn = ang1 < ang0 ? ang1 : ang0, amx = ang1 > ang0 ? ang1 : ang0;
-                amn = ang2 < amn ? ang2 : amn; amx = ang2 > amx ? ang2 : amx;
-                amn = ang3 < amn ? ang3 : amn; amx = ang3 > amx ? ang3 : amx;
-                const double e_reward = sqrt(q1 * (amn / amx));
+                // quad terms of the reward (pre-update coordinates; the Mesh holds the Vertex objects)
+                double e_reward;
+                BqArgs bq;
+                {
+                    const double e0 = c.sc->tmp2[0], e1 = c.sc->tmp2[1], e2 = c.sc->tmp2[2], e3 = c.sc->tmp2[3];
+                    const double d02 = c.sc->tmp2[4], d13 = c.sc->tmp2[5];
+                    const double ang0 = c.sc->ang[0], ang1 = c.sc->ang[1], ang2 = c.sc->ang[2], ang3 = c.sc->ang[3];
+                    // Mesh.get_quality('robust'), C:873-884
+                    double mn = e1 < e0 ? e1 : e0;
+                    mn = e2 < mn ? e2 : mn;
+                    mn = e3 < mn ? e3 : mn;
+                    const double q1 = sqrt(2.0) * mn / (d13 > d02 ? d13 : d02);
+                    double amn = ang1 < ang0 ? ang1 : ang0, amx = ang1 > ang0 ? ang1 : ang0;
+                    amn = ang2 < amn ? ang2 : amn; amx = ang2 > amx ? ang2 : amx;
+                    amn = ang3 < amn ? ang3 : amn; amx = ang3 > amx ? ang3 : amx;
+                    e_reward = uniform_f64(sqrt(q1 * (amn / amx)));
+                    // Mesh.compute_area, C:935-950, left-to-right: ((0.5*e0)*e1)*sin(c1) + ((0.5*e2)*e3)*sin(c3);
+                    // corner_1 == corner angle 0, corner_3 == corner angle 2
+                    bq.half01 = uniform_f64(0.5 * e0 * e1);
+                    bq.half23 = uniform_f64(0.5 * e2 * e3);
+                    bq.q_ang0 = ang0;
+                    bq.q_ang2 = ang2;
+                    bq.ang0 = c.sc->tmp[8];
+                    bq.ang1 = c.sc->tmp[9];
+                }
+                // candidate keys of the four ref_neighbors from the speculative job lanes
+                double kk = 0.0;
+                bool okk = false;
+                int pos = 0;
+                if (lane < 4) {
+                    pos = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
+                    okk = key_from_angles(prm, c.sc->tmp[2 * lane], c.sc->tmp[2 * lane + 1], kk);
+                }
 
                 // update_boundary, M:575-648
                 __syncthreads();
-                double b_reward;
-                int p0, p1, p2, p3;  // ref_neighbors as ring slots
                 if (new_vertex) {
-                    const int id = index;
                     if (lane == 0) {
-                        c.xy[id] = make_double2(new_point.x, new_point.y);
-                        c.id[id] = c.n0 + c.n_new;
-                        c.stamp[id] = kNotCand;
+                        c.xy[index] = make_double2(new_point.x, new_point.y);
+                        c.id[index] = kNewBit | c.n_new;
+                        c.stamp[index] = kNotCand;
                         const int cap = prm.log_cap;
                         if (c.n_new < cap) S.log_vxy[(size_t)c.env * cap + c.n_new] = make_double2(new_point.x, new_point.y);
                     }
                     if (prm.log_cap > 0 && c.n_new >= prm.log_cap) c.status |= kStLogOverflow;
                     c.n_new += 1;
-                    p0 = wrapi(id + 1, n); p1 = wrapi(id - 1, n); p2 = wrapi(id + 2, n); p3 = wrapi(id - 2, n);
+                    bq.mode = 1; bq.a = index; bq.b = 0;
                 } else {
                     // delete the two interior quad vertices (slots mp1, mp2), compacting the ring in LDS
-                    const int lo = mp1 < mp2 ? mp1 : mp2, hi = mp1 < mp2 ? mp2 : mp1;
-                    const int keep0 = c.id[mp0], keep1 = c.id[mp3];
+                    const int lo = vr.lo, hi = vr.hi;
                     for (int base = 0; base < n; base += 64) {
                         const int i = base + lane;
                         double2 vxy = make_double2(0, 0);
@@ -666,29 +848,15 @@ __device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float 
                         __syncthreads();
                     }
                     c.n = n - 2;
-                    // new slots of the kept vertices
-                    const int nn = c.n;
-                    int t0 = mp0 - (mp0 > lo ? 1 : 0) - (mp0 > hi ? 1 : 0);
-                    int t1 = mp3 - (mp3 > lo ? 1 : 0) - (mp3 > hi ? 1 : 0);
-                    (void)keep0; (void)keep1;
-                    const int id = t0 > t1 ? t0 : t1;
-                    p0 = wrapi(id, nn); p1 = wrapi(id - 1, nn); p2 = wrapi(id + 1, nn); p3 = wrapi(id - 2, nn);
-                    mp0 = t0; mp3 = t1;
+                    bq.mode = 2; bq.a = t0; bq.b = t1;
                 }
                 __syncthreads();
                 // remove_reference_candidates(ref_neighbors [+ removed]) then add_reference_candidates in order
                 {
-                    double k = 0.0;
-                    bool okk = false;
-                    if (lane < 4) {
-                        const int pos = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
-                        okk = check_boundary_point(c, prm, pos, k);
-                    }
                     const unsigned long long mk = __ballot(okk);
                     if (lane < 4) {
-                        const int pos = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
                         if (okk) {
-                            c.key[pos] = k;
+                            c.key[pos] = kk;
                             c.stamp[pos] = c.counter + __popcll(mk & ((2ULL << lane) - 1ULL));
                         } else {
                             c.stamp[pos] = kNotCand;
@@ -696,26 +864,29 @@ __device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float 
                     }
                     c.counter += __popcll(mk);
                 }
-                __syncthreads();
-                b_reward = new_vertex ? boundary_quality_new(c, index) : boundary_quality_kept(c, mp0, mp3);
-                c.area -= mesh_area;
-                // get_quality(mesh, 2), M:1733-1740
-                const double quality = e_reward + 1 * (b_reward - 1);
-                // get_speed_penalty, B:434-450
-                const DomConst dc = S.dom_const[c.dom];
-                double speed = 0.0;
-                if (dc.min_area <= mesh_area && mesh_area < dc.crit_area) speed = (mesh_area - dc.crit_area) / (dc.crit_area - dc.min_area);
-                else if (mesh_area < dc.min_area) speed = -1.0;
-                reward += quality + speed;
+                MESHENV_STAMP(c, 6);
                 failed = false;
                 out.valid = true;
                 c.ring_dirty = true;
-                if (c.n <= 5) {  // B:232-238
+                const bool finished = c.n <= 5;  // B:232-238
+                if (finished && c.n == 4) log_quad(c, S, c.id[0], c.id[1], c.id[2], c.id[3]);
+                // current_area -= mesh_area (B:200) happens inside: the area needs sin(corner angles), a stage-B job
+                find_next_state(c, S, bq);
+                MESHENV_STAMP(c, 14);
+                const double mesh_area = bq.mesh_area;
+                // get_quality(mesh, 2), M:1733-1740
+                const double quality = e_reward + 1 * (bq.b_reward - 1);
+                // get_speed_penalty, B:434-450
+                const DomConst &dc = S.dom[c.dom];
+                const double min_area = dc.min_area, crit_area = dc.crit_area;
+                double speed = 0.0;
+                if (min_area <= mesh_area && mesh_area < crit_area) speed = (mesh_area - crit_area) / (crit_area - min_area);
+                else if (mesh_area < min_area) speed = -1.0;
+                reward += quality + speed;
+                if (finished) {
                     reward += 10.0;
                     done = 1;
-                    if (c.n == 4) log_quad(c, S, c.id[0], c.id[1], c.id[2], c.id[3]);
                 }
-                find_next_state(c, S);
             } else {
                 reward += c.n_elem ? -1.0 / c.n_elem : -1.0;  // B:248
             }
@@ -750,14 +921,15 @@ __global__ void __launch_bounds__(64) k_init_domains(DevState S, int cap)
     const int d = blockIdx.x;
     c.lane = lane_id();
     c.env = -1;
+    c.base = 0;
     c.dom = d;
-    const int doff = S.dom_off[d];
-    c.off = 0;
-    c.n0 = S.dom_off[d + 1] - doff;
-    c.n = c.n0;
-    c.area = S.dom_const[d].orig_area;
+    const DomConst dc = S.dom[d];
+    const int doff = dc.off;
+    c.n = dc.n0;
+    c.area = dc.orig_area;
     c.status = 0;
-    c.keys_loaded = true;
+    c.bl = 0.0; c.ct = 1.0; c.st = 0.0;
+    c.obs = 0.0f;
     for (int i = c.lane; i < c.n; i += 64) {
         c.xy[i] = S.dom_xy[doff + i];
         c.id[i] = i;
@@ -765,22 +937,28 @@ __global__ void __launch_bounds__(64) k_init_domains(DevState S, int cap)
     __syncthreads();
     // find_reference_candidates, M:233-261: stable sort by key -> ties in ring order (stamp = -index)
     for (int i = c.lane; i < c.n; i += 64) {
-        double k = 0.0;
-        const bool ok = check_boundary_point(c, S.prm, i, k);
+        double cc, dd, k = 0.0;
+        key_angle_terms(c, i, 0, cc, dd);
+        const double a0 = cw_finish(atan2_nc(cc, dd));
+        key_angle_terms(c, i, 1, cc, dd);
+        const double a1 = cw_finish(atan2_nc(cc, dd));
+        const bool ok = key_from_angles(S.prm, a0, a1, k);
         c.key[i] = k;
         c.stamp[i] = ok ? -i : kNotCand;
     }
-    c.bl = 0.0;
-    c.obs = 0.0f;
-    find_next_state(c, S);
+    BqArgs bq;
+    bq.mode = 0; bq.a = 0; bq.b = 0; bq.ang0 = 0; bq.ang1 = 0; bq.q_ang0 = 0; bq.q_ang2 = 0; bq.half01 = 0; bq.half23 = 0;
+    find_next_state(c, S, bq);
     for (int i = c.lane; i < c.n; i += 64) {
         S.dom_key[doff + i] = c.key[i];
         S.dom_stamp[doff + i] = c.stamp[i];
     }
     if (c.lane < kObsDim) S.dom_obs[(size_t)d * kObsDim + c.lane] = c.obs;
     if (c.lane == 0) {
-        S.dom_ref[d] = c.ref;
-        S.dom_bl[d] = c.bl;
+        S.dom[d].ref = c.ref;
+        S.dom[d].bl = c.bl;
+        S.dom[d].ct = c.ct;
+        S.dom[d].st = c.st;
     }
 }
 
@@ -797,9 +975,8 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
         return;
     }
     c.env = env;
-    c.off = S.env_off[env];
-    c.n0 = S.env_off[env + 1] - c.off;
-    c.dom = S.scal[env].dom;
+    c.base = (size_t)env * S.cap;
+    c.dom = uniform_i32(S.scal[env].dom);
     reset_from_domain(c, S);
     if (first && c.lane == 0) {
         EnvCounters z;
@@ -811,7 +988,10 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
 }
 
 // n_steps consecutive steps of every env in one launch (n_steps = 1 is meshenv_step).
-__global__ void __launch_bounds__(64)
+#ifndef MESHENV_STEP_WAVES_PER_SIMD
+#define MESHENV_STEP_WAVES_PER_SIMD 2
+#endif
+__global__ void __launch_bounds__(64, MESHENV_STEP_WAVES_PER_SIMD)
 k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, float *__restrict__ obs_out,
        double *__restrict__ reward, uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
        float *__restrict__ term_obs, int auto_reset)
@@ -821,14 +1001,26 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     carve_lds(c, smem, cap);
     const int env = blockIdx.x;
     const int E = S.n_envs;
-    load_env(c, S, env, n_steps > 1);
-    unsigned long long st_steps = 0, st_valid = 0, st_sum = 0, st_sumv = 0;
+    const float *a = actions + (size_t)env * 3;
+    float a0 = a[0], a1 = a[1], a2 = a[2];
+#ifdef MESHENV_STAMPS
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime();
+#endif
+    load_env(c, S, env);
+#ifdef MESHENV_STAMPS
+    const unsigned long long stamp_t1 = __builtin_amdgcn_s_memrealtime();
+    if (c.lane < 16) c.sc->stamps[c.lane] = 0;
+    __syncthreads();
+#endif
+    unsigned long long st_valid = 0, st_sum = 0, st_sumv = 0;
     for (int t = 0; t < n_steps; t++) {
-        const float *a = actions + ((size_t)t * E + env) * 3;
-        const float a0 = a[0], a1 = a[1], a2 = a[2];
+        if (t > 0) {
+            const float *at = actions + ((size_t)t * E + env) * 3;
+            a0 = at[0]; a1 = at[1]; a2 = at[2];
+        }
         const int n_before = c.n;
         const StepResult r = env_step(c, S, a0, a1, a2);
-        st_steps += 1;
         st_sum += (unsigned long long)n_before;
         if (r.valid) { st_valid += 1; st_sumv += (unsigned long long)n_before; }
         const size_t o = (size_t)t * E + env;
@@ -844,11 +1036,25 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     }
     if (c.lane < kObsDim) obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
     store_env(c, S);
+#ifdef MESHENV_STAMPS
+    // diagnostic build only: per-wave timeline (100 MHz realtime ticks) instead of the work counters
     if (c.lane == 0) {
-        EnvCounters k = S.cnt[env];
-        k.steps += st_steps; k.valid += st_valid; k.sum_n += st_sum; k.sum_n_valid += st_sumv;
+        EnvCounters k;
+        k.steps = stamp_t0; k.valid = stamp_t1; k.sum_n = __builtin_amdgcn_s_memrealtime();
+        k.sum_n_valid = st_valid | ((unsigned long long)(a0 <= -0.5f ? 1 : (a0 >= 0.5f ? 2 : 0)) << 8);
         S.cnt[env] = k;
     }
+    __syncthreads();
+    if (c.lane == 0) c.sc->stamps[15] = __builtin_amdgcn_s_memtime() - stamp_c0;
+    __syncthreads();
+    if (c.lane < 16) S.dbg[(size_t)env * 16 + c.lane] = c.sc->stamps[c.lane];
+#else
+    if (c.lane == 0) {
+        EnvCounters k = S.cnt[env];
+        k.steps += (unsigned long long)n_steps; k.valid += st_valid; k.sum_n += st_sum; k.sum_n_valid += st_sumv;
+        S.cnt[env] = k;
+    }
+#endif
 }
 
 }  // namespace meshenv

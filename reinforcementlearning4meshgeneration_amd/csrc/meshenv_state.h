@@ -1,9 +1,12 @@
 // meshenv_state.h -- HBM layout of the vectorised BoudaryEnv state (shared by kernels and the C-ABI host code).
 //
-// Structure-of-arrays over environments; each environment owns one contiguous ring segment
-// [env_off[e], env_off[e] + n0) in the flat ring arrays, so a wavefront stages its ring with fully
-// coalesced 16-byte loads.  Domains (the initial polygons) live in a separate table together with
-// everything reset() computes for them, so reset is a copy.
+// Structure-of-arrays over environments with a UNIFORM ring stride `cap` (max ring length of the batch,
+// rounded up to 16): environment e owns slots [e*cap, e*cap + n0) of every ring array.  A wavefront can
+// therefore issue all of its loads (scalars, action, ring coords/ids/keys/stamps) in one go, with no
+// dependent offset lookup -- one HBM round trip per step -- and stages its ring with coalesced 16-byte loads.
+// 288 GB of HBM make the padding irrelevant (65536 envs x 640 slots x 32 B = 1.3 GB).
+// Domains (the initial polygons) live in a separate table together with everything reset() computes for
+// them, so reset is a copy.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -26,19 +29,24 @@ struct alignas(64) EnvScalars {
     int32_t dom;       // domain index
     double bl;         // current_point_environment.base_length
     double area;       // current_area
-    double pad[2];
+    double ct, st;     // cos / sin of the action frame angle 2*pi - atan2(right - ref) (D:69-73), per state
 };
 
 struct alignas(32) EnvCounters {
     unsigned long long steps, valid, sum_n, sum_n_valid;
 };
 
-// per-domain constants
-struct alignas(32) DomConst {
+// per-domain constants + the scalars reset() derives
+struct alignas(64) DomConst {
     double orig_area;  // Boundary2D.poly_area()
     double min_area;   // estimated_area_range[0] ** 2
     double crit_area;  // estimated_area_range[1] ** 2
-    double pad;
+    double bl;         // base_length of the first observation
+    double ct, st;     // action frame of the first observation
+    int32_t off;       // first slot in the dom_* arrays
+    int32_t n0;        // ring length
+    int32_t ref;       // first reference vertex
+    int32_t pad;
 };
 
 struct Params {
@@ -49,27 +57,27 @@ struct Params {
 struct DevState {
     // ---- domain table
     int n_domains;
-    const int32_t *dom_off;   // [D+1]
+    DomConst *dom;            // [D]
     const double2 *dom_xy;    // [sum n0]
     double *dom_key;          // [sum n0] reset-time candidate keys
     int32_t *dom_stamp;       // [sum n0] -index, or kNotCand
-    const DomConst *dom_const;  // [D]
     float *dom_obs;           // [D][18] first observation
-    int32_t *dom_ref;         // [D]
-    double *dom_bl;           // [D]
     // ---- environments
     int n_envs;
-    const int32_t *env_off;   // [E+1]
-    double2 *ring_xy;         // ring coordinates (x, y)
-    int32_t *ring_id;         // ring slot -> global vertex id
-    double *ring_key;         // cached candidate key per slot
-    int32_t *ring_stamp;      // insertion stamp per slot (kNotCand: not a candidate)
+    int cap;                  // ring stride
+    double2 *ring_xy;         // [E][cap] ring coordinates (x, y)
+    int32_t *ring_id;         // [E][cap] ring slot -> global vertex id
+    double *ring_key;         // [E][cap] cached candidate key per slot
+    int32_t *ring_stamp;      // [E][cap] insertion stamp per slot (kNotCand: not a candidate)
     EnvScalars *scal;         // [E]
     EnvCounters *cnt;         // [E]
     float *obs_cache;         // [E][18] observation of the current state
     // ---- logs (generated_meshes / boundary.vertices), optional
     int32_t *log_quads;       // [E][log_cap][4]
     double2 *log_vxy;         // [E][log_cap]
+#ifdef MESHENV_STAMPS
+    unsigned long long *dbg;  // [E][16] diagnostic build: in-kernel timeline stamps
+#endif
     Params prm;
 };
 
