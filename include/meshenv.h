@@ -187,6 +187,15 @@ int meshenv_counters(MeshEnv *h, uint64_t *out_host);
 int meshenv_set_timing(MeshEnv *h, int enable);
 int meshenv_kernel_times(MeshEnv *h, float *ms_host, int cap, int32_t *n_out);
 
+/*
+ * Test hook: evaluate one device geometry primitive on n items (in_per_item doubles each) and copy the results
+ * back, so the parity tests can compare the device primitives with the oracle's one by one.
+ *   what 0 round(python float, 4)   1 round(np.float64, 4)   2 Vertex.to_find_clockwise_angle (6 doubles: s, p1, p2)
+ *        3 Segment.is_cross (8 doubles: a1, a2, b1, b2)  4 collinearity class, fast + 2*exact (2 doubles: c, d)
+ *        5 round(np.float32, 4)      6 Point2D.distance_to (4 doubles)
+ */
+int meshenv_selftest(int device, int what, int n, int in_per_item, const double *in_host, double *out_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,20 @@ __device__ __forceinline__ P2 mkp(double x, double y)
 }
 
 // ---------------------------------------------------------------------------------- rounding
+// r / 1e4 for a non-negative integer-valued r.  For r < 2^33 the three-operation FMA sequence below returns the
+// correctly rounded quotient -- checked exhaustively against IEEE division for every integer in [0, 2^33)
+// (tools/verify_div1e4.c) -- at a third of the latency of the fp64 divide; larger r take the divide.
+__device__ MESHENV_NOINLINE double div1e4_slow(double r) { return r / 1e4; }
+__device__ __forceinline__ double div1e4(double r)
+{
+    if (r < 8589934592.0) {
+        const double q0 = r * 1e-4;
+        const double rem = fma(-q0, 1e4, r);
+        return fma(rem, 1e-4, q0);
+    }
+    return div1e4_slow(r);
+}
+
 // Python's round(float, 4): correctly rounded decimal rounding of the exact binary value, ties to even.
 // y = |x|*1e4 (rounded) and e = fma(|x|,1e4,-y) (exact residual) give the exact product as y + e, so the
 // comparison of its fractional part against 0.5 is exact; r/1e4 with IEEE division is the double nearest
@@ -46,11 +60,15 @@ __device__ __forceinline__ double round4_py(double x)
     double r = f;
     if (s > 0.0) r = f + 1.0;
     else if (s == 0.0 && (((long long)f) & 1LL)) r = f + 1.0;
-    return copysign(r / 1e4, x);
+    return copysign(div1e4(r), x);
 }
 
 // round(np.float64, 4): numpy's multiply / rint / divide
-__device__ __forceinline__ double round4_np(double x) { return rint(x * 1e4) / 1e4; }
+__device__ __forceinline__ double round4_np(double x)
+{
+    const double r = rint(x * 1e4);
+    return copysign(div1e4(fabs(r)), r);
+}
 
 // round(np.float32, 4): the same in float32
 __device__ __forceinline__ float round4_npf(float x) { return rintf(x * 1e4f) / 1e4f; }
@@ -104,18 +122,40 @@ __device__ __forceinline__ double cw(P2 s, P2 p1, P2 p2)
     return cw_finish(atan2_nc(c, d));
 }
 
-// True when round(sin(cw(...)), 4) can only be non-zero.  The rounded angle is within 5e-5 rad of the
-// true angle, so if the true angle is more than 1e-3 rad away from every multiple of pi (|tan| > 1e-3)
-// the rounded one is at least 9.5e-4 away and |sin| >= 9.4e-4, which rounds to a non-zero 4-decimal
-// value.  Lets Segment.straddle skip atan2/sin for every non-degenerate configuration; the exact path is
-// taken otherwise, so results are identical to the unfiltered evaluation.
-__device__ __forceinline__ bool surely_not_collinear(double c, double d)
+// sin_rounds_to_zero(c, d)  ==  (round(sin(cw_angle), 4) == 0)  with cw_angle = the 1e-4-quantised clockwise angle
+// whose atan2 arguments are (c, d) -- the collinearity test of Segment.straddle (C:498-500).
+//
+// The rounded angle a is a multiple of 1e-4 in [0, 2pi]; |sin(a)| < 5e-5 only for a in {0.0, 3.1416, 6.2832}.
+//  * |c| > 1e-3 |d|: the true angle is > 9.99e-4 rad away from every multiple of pi, the rounded one > 9.4e-4:
+//    never zero.  (Every non-degenerate configuration ends here: two cross products, no transcendental.)
+//  * otherwise r = c/d, |r| <= 1e-3 and atan(r) = r to within 3.4e-10, so the angle is known to 3.4e-10 and each of
+//    the four sign cases below reduces "a in {0, 3.1416, 6.2832}" to one comparison of |r| against the matching
+//    rounding boundary.  Within 1e-8 of a boundary (and for d == 0, which implies c == 0) the reference
+//    evaluation (atan2, round, sin, round) is used, so the result is the reference's in every case.
+__device__ __forceinline__ bool sin_rounds_to_zero_exact(double c, double d)
+{
+    return round4_py(sin_nc(cw_finish(atan2_nc(c, d)))) == 0.0;
+}
+
+__device__ __forceinline__ bool sin_rounds_to_zero(double c, double d)
 {
 #ifdef MESHENV_NO_FILTERS
-    (void)c; (void)d;
-    return false;
+    return sin_rounds_to_zero_exact(c, d);
 #else
-    return fabs(c) > 1e-3 * fabs(d);
+    if (fabs(c) > 1e-3 * fabs(d)) return false;
+    if (d != 0.0) {
+        const double r = c / d;
+        double x, thr;
+        if (d > 0.0) {
+            if (signbit(c)) { x = -r; thr = 5e-5; }                      // theta = -t >= +0: a = round(theta) == 0.0
+            else { x = r; thr = 2 * kPi - 6.28315; }                     // theta < 0: a = round(2pi + theta) == 6.2832
+        } else {
+            if (!signbit(c)) { x = -r; thr = 3.14165 - kPi; }            // t = pi + r: a = round(pi + |r|) == 3.1416
+            else { x = r; thr = kPi - 3.14155; }                         // t = -pi + r: a = round(pi - r) == 3.1416
+        }
+        if (fabs(x - thr) > 1e-8) return x < thr;
+    }
+    return sin_rounds_to_zero_exact(c, d);
 #endif
 }
 
@@ -128,12 +168,8 @@ __device__ MESHENV_NOINLINE bool straddle(P2 p1, P2 p2, P2 q1, P2 q2)
     double c1, d1, c2, d2;
     cw_terms(p1, q1, p2, c1, d1);
     cw_terms(p1, q2, p2, c2, d2);
-    bool collinear = false;
-    if (!surely_not_collinear(c1, d1) && !surely_not_collinear(c2, d2)) {
-        const double s1 = round4_py(sin_nc(cw_finish(atan2_nc(c1, d1))));
-        const double s2 = round4_py(sin_nc(cw_finish(atan2_nc(c2, d2))));
-        collinear = (s1 == s2) && (s2 == 0.0);
-    }
+    // s1 == s2 and s2 == 0 (C:498-500); both roundings are (+-)0 then, and -0.0 == 0.0
+    const bool collinear = sin_rounds_to_zero(c1, d1) && sin_rounds_to_zero(c2, d2);
     if (collinear) {
         const double l1 = dist(p1, p2), l2 = dist(q1, q2);
         if (l1 > l2) {

@@ -180,7 +180,8 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
 
     CREATE_HIP(hipSetDevice(device));
     if (lds > 64 * 1024) {
-        CREATE_HIP(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_init_domains, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -288,8 +289,12 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
     if (n_steps <= 0) return fail_arg(h, "meshenv_rollout: n_steps must be positive");
     const size_t slot = (size_t)(h->ev_count % MESHENV_TIMING_POOL);
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2 * slot], h->stream));
-    hipLaunchKernelGGL(k_step, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, n_steps, actions_dev, obs_dev,
-                       reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
+    if (n_steps == 1)
+        hipLaunchKernelGGL(k_step<false>, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, 1, actions_dev, obs_dev,
+                           reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
+    else
+        hipLaunchKernelGGL(k_step<true>, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, n_steps, actions_dev, obs_dev,
+                           reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) {
         HIP_TRY(h, hipEventRecord(h->ev[2 * slot + 1], h->stream));
@@ -450,6 +455,41 @@ int meshenv_debug_stamps(MeshEnv *h, uint64_t *out_host)
     return MESHENV_OK;
 }
 #endif
+
+// ---- primitive self-test hook (tests/test_gpu_primitives.py): evaluates the device geometry primitives on
+// caller-supplied host arrays so that they can be compared with the CPU oracle's.
+__global__ void k_selftest(int what, int n, const double *in, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (what == 0) out[i] = round4_py(in[i]);
+    else if (what == 1) out[i] = round4_np(in[i]);
+    else if (what == 2) out[i] = cw(mkp(in[6 * i], in[6 * i + 1]), mkp(in[6 * i + 2], in[6 * i + 3]), mkp(in[6 * i + 4], in[6 * i + 5]));
+    else if (what == 3) out[i] = is_cross(mkp(in[8 * i], in[8 * i + 1]), mkp(in[8 * i + 2], in[8 * i + 3]), mkp(in[8 * i + 4], in[8 * i + 5]),
+                                          mkp(in[8 * i + 6], in[8 * i + 7])) ? 1.0 : 0.0;
+    else if (what == 4) out[i] = (sin_rounds_to_zero(in[2 * i], in[2 * i + 1]) ? 1.0 : 0.0) + (sin_rounds_to_zero_exact(in[2 * i], in[2 * i + 1]) ? 2.0 : 0.0);
+    else if (what == 5) out[i] = (double)round4_npf((float)in[i]);
+    else if (what == 6) out[i] = dist(mkp(in[4 * i], in[4 * i + 1]), mkp(in[4 * i + 2], in[4 * i + 3]));
+}
+
+int meshenv_selftest(int device, int what, int n, int in_per_item, const double *in_host, double *out_host)
+{
+    if (n <= 0 || !in_host || !out_host || in_per_item <= 0) return MESHENV_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return MESHENV_E_HIP;
+    double *din = nullptr, *dout = nullptr;
+    if (hipMalloc(&din, sizeof(double) * (size_t)n * in_per_item) != hipSuccess) return MESHENV_E_HIP;
+    if (hipMalloc(&dout, sizeof(double) * (size_t)n) != hipSuccess) { (void)hipFree(din); return MESHENV_E_HIP; }
+    int rc = MESHENV_OK;
+    if (hipMemcpy(din, in_host, sizeof(double) * (size_t)n * in_per_item, hipMemcpyHostToDevice) != hipSuccess) rc = MESHENV_E_HIP;
+    if (rc == MESHENV_OK) {
+        hipLaunchKernelGGL(k_selftest, dim3((n + 63) / 64), dim3(64), 0, nullptr, what, n, din, dout);
+        if (hipDeviceSynchronize() != hipSuccess) rc = MESHENV_E_HIP;
+    }
+    if (rc == MESHENV_OK && hipMemcpy(out_host, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = MESHENV_E_HIP;
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    return rc;
+}
 
 int meshenv_set_timing(MeshEnv *h, int enable)
 {

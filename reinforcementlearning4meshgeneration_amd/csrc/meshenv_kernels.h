@@ -987,10 +987,14 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
     if (obs_out && c.lane < kObsDim) obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
 }
 
-// n_steps consecutive steps of every env in one launch (n_steps = 1 is meshenv_step).
+// One step() of every env (kMulti = false, meshenv_step) or n_steps consecutive steps in one launch
+// (kMulti = true, meshenv_rollout).  Two instantiations on purpose: inside the multi-step loop the compiler hoists
+// every lane predicate and table of the step body into the loop preheader (hundreds of instructions and SGPR
+// spills that a single step would pay for nothing).
 #ifndef MESHENV_STEP_WAVES_PER_SIMD
 #define MESHENV_STEP_WAVES_PER_SIMD 2
 #endif
+template <bool kMulti>
 __global__ void __launch_bounds__(64, MESHENV_STEP_WAVES_PER_SIMD)
 k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, float *__restrict__ obs_out,
        double *__restrict__ reward, uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
@@ -1014,8 +1018,9 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     __syncthreads();
 #endif
     unsigned long long st_valid = 0, st_sum = 0, st_sumv = 0;
-    for (int t = 0; t < n_steps; t++) {
-        if (t > 0) {
+    const int T = kMulti ? n_steps : 1;
+    for (int t = 0; t < T; t++) {
+        if (kMulti && t > 0) {
             const float *at = actions + ((size_t)t * E + env) * 3;
             a0 = at[0]; a1 = at[1]; a2 = at[2];
         }
@@ -1044,14 +1049,13 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
         k.sum_n_valid = st_valid | ((unsigned long long)(a0 <= -0.5f ? 1 : (a0 >= 0.5f ? 2 : 0)) << 8);
         S.cnt[env] = k;
     }
-    __syncthreads();
     if (c.lane == 0) c.sc->stamps[15] = __builtin_amdgcn_s_memtime() - stamp_c0;
     __syncthreads();
     if (c.lane < 16) S.dbg[(size_t)env * 16 + c.lane] = c.sc->stamps[c.lane];
 #else
     if (c.lane == 0) {
         EnvCounters k = S.cnt[env];
-        k.steps += (unsigned long long)n_steps; k.valid += st_valid; k.sum_n += st_sum; k.sum_n_valid += st_sumv;
+        k.steps += (unsigned long long)T; k.valid += st_valid; k.sum_n += st_sum; k.sum_n_valid += st_sumv;
         S.cnt[env] = k;
     }
 #endif

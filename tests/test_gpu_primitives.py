@@ -1,0 +1,96 @@
+"""GPU: device geometry primitives (through meshenv_selftest) against the CPU oracle's, item by item.
+
+Bit-exact where the arithmetic is IEEE-determined (roundings, the collinearity classification against its own
+exact evaluation, is_cross); clockwise angles may differ from the host libm only through a last-bit atan2
+difference landing on a 1e-4 rounding boundary, which the random sample never hits (asserted equal)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(what, items):
+    from reinforcementlearning4meshgeneration_amd import _capi
+    L = _capi.load()
+    items = np.ascontiguousarray(items, np.float64)
+    n = items.shape[0]
+    per = 1 if items.ndim == 1 else items.shape[1]
+    out = np.zeros(n, np.float64)
+    rc = L.meshenv_selftest(0, what, n, per, items.ctypes.data, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def _adversarial_round_inputs(rng):
+    k = rng.integers(0, 70000, 20000).astype(np.float64)
+    half = (k + 0.5) / 1e4                       # decimal ties, never exactly representable
+    xs = [half, np.nextafter(half, 0), np.nextafter(half, 10), rng.uniform(-7, 7, 200000),
+          rng.uniform(-1e-4, 1e-4, 20000), np.array([0.0, -0.0, 0.03125, 0.09375, 0.00005, 1e-300, 123456.78125, 9e5, 1e9, -2.5e-5]),
+          k / 1e4, -(k / 1e4), rng.uniform(-2000, 2000, 100000)]
+    return np.concatenate(xs)
+
+
+def test_round4_variants(oracle_lib):
+    rng = np.random.default_rng(0)
+    x = _adversarial_round_inputs(rng)
+    ref_py = np.array([oracle_lib.meshenv_ref_round4_py(v) for v in x])
+    ref_np = np.array([oracle_lib.meshenv_ref_round4_np(v) for v in x])
+    got_py, got_np = _run(0, x), _run(1, x)
+    assert np.array_equal(got_py.view(np.int64), ref_py.view(np.int64))     # bit-exact incl. signed zeros
+    assert np.array_equal(got_np.view(np.int64), ref_np.view(np.int64))
+    # and the oracle's round4_py is Python's round()
+    sample = x[::97]
+    assert all(float(a) == round(float(b), 4) for a, b in zip(ref_py[::97], sample))
+    xf = rng.uniform(-7, 7, 100000).astype(np.float32)
+    ref_f = np.array([oracle_lib.meshenv_ref_round4_npf(float(v)) for v in xf], np.float32)
+    got_f = _run(5, xf.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got_f.view(np.int32), ref_f.view(np.int32))
+
+
+def test_collinearity_classification_is_exact():
+    rng = np.random.default_rng(1)
+    thr = np.array([5e-5, 2 * np.pi - 6.28315, 3.14165 - np.pi, np.pi - 3.14155])
+    d = rng.uniform(0.1, 50, 400000) * rng.choice([-1, 1], 400000)
+    r = np.concatenate([rng.uniform(-2e-3, 2e-3, 200000),
+                        (thr[rng.integers(0, 4, 100000)] + rng.uniform(-3e-8, 3e-8, 100000)) * rng.choice([-1, 1], 100000),
+                        rng.uniform(-1.2e-4, 1.2e-4, 100000)])
+    c = r * d
+    special = np.array([[0.0, 1.0], [-0.0, 1.0], [0.0, -1.0], [-0.0, -1.0], [0.0, 0.0], [-0.0, 0.0], [0.0, -0.0],
+                        [1.0, 0.0], [-1.0, 0.0], [1e-3, 1.0], [-1e-3, -1.0]])
+    items = np.concatenate([np.stack([c, d], axis=1), special])
+    out = _run(4, items)
+    fast, exact = (out.astype(int) & 1), (out.astype(int) >> 1)
+    assert np.array_equal(fast, exact)
+    assert exact.sum() > 1000 and (1 - exact).sum() > 1000
+
+
+def test_clockwise_angle_and_is_cross_match_oracle(oracle_lib):
+    rng = np.random.default_rng(2)
+    n = 60000
+    pts = np.round(rng.uniform(-5, 15, (n, 6)), 4)
+    # integer-grid and collinear configurations (the built-in domains are full of them)
+    grid = rng.integers(-3, 13, (n, 6)).astype(np.float64)
+    items = np.concatenate([pts, grid])
+    ref = np.array([oracle_lib.meshenv_ref_cw(*row) for row in items])
+    got = _run(2, items)
+    assert np.array_equal(got, ref)
+    segs = np.concatenate([np.round(rng.uniform(0, 6, (n, 8)), 4), rng.integers(0, 7, (n, 8)).astype(np.float64)])
+    a1, a2, b1, b2 = (np.ascontiguousarray(segs[:, 2 * k:2 * k + 2]) for k in range(4))
+    ref_x = np.array([oracle_lib.meshenv_ref_is_cross(a1[i], a2[i], b1[i], b2[i]) for i in range(len(segs))], np.float64)
+    got_x = _run(3, segs)
+    assert np.array_equal(got_x, ref_x)
+    assert 0.05 < ref_x.mean() < 0.95
+
+
+def test_distance_within_one_ulp_of_oracle():
+    """The device squares with a*a, the reference with libm pow(a, 2.0): at most one ulp apart."""
+    rng = np.random.default_rng(3)
+    p = np.round(rng.uniform(-20, 20, (100000, 4)), 4)
+    got = _run(6, p)
+    import math
+    ref = np.array([math.sqrt((a - c) ** 2 + (b - d) ** 2) for a, b, c, d in p])
+    ulp = np.spacing(ref)
+    assert np.all(np.abs(got - ref) <= ulp)
+    assert (got != ref).mean() < 0.01

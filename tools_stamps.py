@@ -47,3 +47,11 @@ for label,m in [("VALID rule0",valid&(rule==0)),("VALID rule+-1",valid&(rule!=0)
     print("   end tail mean=%.2f"%(((t2[m]-prev)*tick).mean()))
 cyc=st[:,15].astype(np.float64); durr=(t2-t0).astype(np.float64)*10.0  # ns
 print("shader clock GHz (s_memtime/s_memrealtime): mean=%.3f p10=%.3f p90=%.3f"%((cyc/durr).mean(), np.percentile(cyc/durr,10), np.percentile(cyc/durr,90)))
+order=np.argsort(-dur)[:12]
+print("slowest waves: env dur start valid rule stage-deltas")
+for e in order:
+    prev=t1[e]; ds=[]
+    for k in range(1,15):
+        if st[e,k]>0: ds.append(f"{k}:{(st[e,k]-prev)*tick:.1f}"); prev=st[e,k]
+    print(e, f"{dur[e]:.1f}", f"{(t0[e]-base)*tick:.1f}", int(valid[e]), int(rule[e]), " ".join(ds), f"tail:{(t2[e]-prev)*tick:.1f}")
+print("valid dur percentiles 50/90/99/100:", np.percentile(dur[valid],[50,90,99,100]))
