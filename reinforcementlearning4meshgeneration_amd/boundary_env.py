@@ -1,0 +1,111 @@
+"""Drop-in Gym surface of the reference's ``BoudaryEnv`` (rl/boundary_env.py:18) over the HIP engine.
+
+``BoudaryEnv(boundary)`` keeps the reference's constructor, attributes and return conventions:
+
+* legacy API (rl/boundary_env.py):  ``reset(static=False) -> obs``;
+  ``step(action) -> (obs | None, np.float64 reward, bool done, {'is_complete': bool})``
+* Gymnasium API (v2/src/mesh_rl/envs/boundary_env.py:136-184, 388-457), selected with ``api="gymnasium"``:
+  ``reset(*, seed=None, static=False, options=None) -> (obs, {})``;
+  ``step(action) -> (obs, reward, terminated, truncated, info)`` with
+  ``terminated = done and is_complete``, ``truncated = done and not is_complete``.
+
+It is a one-environment ``MeshVecEnv``: every call is a kernel launch plus a device->host copy, so it exists
+for API compatibility (SB3 wraps it in its own DummyVecEnv) and for evaluation scripts; training at scale
+should hand ``MeshVecEnv`` to SB3 directly.  There is no CPU path: without the GPU library it raises.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .domains import Point, read_polygon
+from .vec_env import MeshVecEnv, make_spaces
+
+
+class BoudaryEnv:  # the reference's spelling
+    metadata = {"render.modes": ["human"]}
+    TYPE_THRESHOLD = 0.3
+
+    def __init__(self, boundary: Sequence[Point], experiment_version=None, env_name=None, *, device: int = 0,
+                 api: str = "legacy", log_capacity: int = 4096):
+        if hasattr(boundary, "vertices"):  # a reference-style Boundary2D
+            boundary = [(v.x, v.y) for v in boundary.vertices]
+        if api not in ("legacy", "gymnasium"):
+            raise ValueError("api must be 'legacy' or 'gymnasium'")
+        self.api = api
+        self.points = [tuple(p) for p in boundary]
+        self.experiment_version = experiment_version if experiment_version else "test"
+        self.env_name = env_name if env_name is not None else 1
+        self.observation_space, self.action_space = make_spaces()
+        self._vec = MeshVecEnv([self.points], n_envs=1, device=device, auto_reset=False, log_capacity=log_capacity)
+        self.original_area = self._vec.constants[0].original_area
+        self.average_edge_length = self._vec.constants[0].average_edge_length
+        self.estimated_area_range = (self._vec.constants[0].est_min_l, self._vec.constants[0].est_crit_l)
+        self.neighbor_num, self.radius_num, self.radius = 6, 3, 4
+        self.history_info = {-1: [], 1: [], 0: []}
+        self.current_state = None
+
+    @classmethod
+    def from_domain_file(cls, path, **kw):
+        """v2/src/mesh_rl/envs/boundary_env.py:45-56"""
+        return cls(read_polygon(path), **kw)
+
+    # ------------------------------------------------------------------ Gym surface
+    def reset(self, *, seed=None, static=False, options=None):
+        if static:
+            raise NotImplementedError("static=True (observation with area_ratio forced to 0) is not part of the hot path")
+        if seed is not None and hasattr(self.action_space, "seed"):
+            self.action_space.seed(seed)
+        obs = self._vec.reset().cpu().numpy()[0].copy()
+        self.current_state = obs
+        return (obs, {}) if self.api == "gymnasium" else obs
+
+    def step(self, action):
+        import torch
+        a = torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(1, 3), device=self._vec.device)
+        obs, rew, done, comp = self._vec.step(a)
+        none = bool(int(self._vec.status().cpu()[0]) & 1)
+        obs_np = None if none else obs.cpu().numpy()[0].copy()
+        reward = np.float64(rew.cpu()[0].item())
+        done_b, comp_b = bool(done.cpu()[0]), bool(comp.cpu()[0])
+        self.current_state = obs_np
+        info = {"is_complete": comp_b}
+        if self.api == "gymnasium":
+            return obs_np, reward, done_b and comp_b, done_b and not comp_b, info
+        return obs_np, reward, done_b, info
+
+    def seed(self, seed=None):
+        if hasattr(self.action_space, "seed"):
+            self.action_space.seed(seed)
+        return [seed]
+
+    def render(self, mode="human"):
+        print(f"Generated elements: {len(self.generated_meshes)}")
+
+    def close(self):
+        self._vec.close()
+
+    # ------------------------------------------------------------------ attributes the reference's callers read
+    @property
+    def generated_meshes(self):
+        """List of quads, each a [4, 2] array of vertex coordinates (rl/boundary_env.py:192)."""
+        quads, vxy = self._vec.get_elements(0)
+        return [vxy[q] for q in quads]
+
+    def get_elements(self):
+        """(quads [n,4] vertex ids, vertices [m,2]) -- what write_generated_elements_2_file consumes."""
+        return self._vec.get_elements(0)
+
+    @property
+    def failed_num(self):
+        return self._vec.get_state(0)["failed_num"]
+
+    @property
+    def current_area(self):
+        return self._vec.get_state(0)["current_area"]
+
+    @property
+    def updated_boundary(self):
+        """Current front as an [n, 2] array (ring order)."""
+        return self._vec.get_state(0)["ring_xy"]

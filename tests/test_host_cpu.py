@@ -1,0 +1,110 @@
+"""CPU (-m "not gpu"): host logic, domain constants against the reference's own numbers, the C-ABI library's
+exports, and the no-CPU-fallback rule."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, ROOT, golden_names
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from reinforcementlearning4meshgeneration_amd import _capi
+    from reinforcementlearning4meshgeneration_amd.build import LIB_PATH
+    assert os.path.exists(LIB_PATH), "run `python -m reinforcementlearning4meshgeneration_amd.build` first"
+    L = _capi.load()
+    header = open(os.path.join(ROOT, "include", "meshenv.h")).read()
+    declared = sorted(set(re.findall(r"\b(meshenv_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/meshenv.h but not exported"
+    assert sorted(_capi.EXPORTS) == declared
+    assert L.meshenv_abi_version() == 1
+    p = _capi.default_params()
+    assert (p.neighbor_num, p.radius_num, p.fail_limit) == (6, 3, 100)
+    assert p.radius == 4 and abs(p.max_ref_angle - 0.972 * np.pi) < 1e-15 and p.key_lambda == 0.618
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a GPU the product path must fail loudly, never compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from reinforcementlearning4meshgeneration_amd import _capi, boundary
+    from reinforcementlearning4meshgeneration_amd.vec_env import MeshVecEnv
+    with pytest.raises(_capi.MeshEnvError):
+        MeshVecEnv([boundary(0)], n_envs=4)
+    import ctypes as C
+    L = _capi.load()
+    h = C.c_void_p()
+    offs = (C.c_int32 * 2)(0, 4)
+    xy = (C.c_double * 8)(0, 0, 0, 1, 1, 1, 1, 0)
+    consts = (C.c_double * 3)(1, 1, 1)
+    dom = (C.c_int32 * 1)(0)
+    rc = L.meshenv_create(0, 1, offs, xy, consts, 1, dom, None, None, C.byref(h))
+    assert rc == -2 and not h.value
+    assert b"no HIP device" in L.meshenv_last_error(None) or b"hip" in L.meshenv_last_error(None).lower()
+
+
+def test_product_code_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing in the package may import, load or link it."""
+    pkg = os.path.join(ROOT, "reinforcementlearning4meshgeneration_amd")
+    banned = re.compile(r"(from\s+oracle|import\s+oracle|libmeshenv_ref|meshenv_ref_|ref_lib|ref_harness)")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not banned.search(text), f"{f} references the oracle"
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_domain_constants_match_reference(name):
+    from reinforcementlearning4meshgeneration_amd.domains import domain_constants
+    tr = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    pts = [tuple(p) for p in tr["domain_xy"]]
+    c = domain_constants(pts)
+    ref = tr["consts"]
+    # poly_area goes through BLAS dot (summation order may differ by CPU): 1e-13; the rest is exact
+    assert abs(c.original_area - ref[0]) <= 1e-13 * abs(ref[0])
+    assert c.average_edge_length == ref[1]
+    assert c.est_min_l == ref[2] and c.est_crit_l == ref[3]
+
+
+def test_builtin_and_random_domains():
+    from reinforcementlearning4meshgeneration_amd import domains as D
+    assert len(D.boundary(0)) == 30 and len(D.boundary(1)) == 44 and len(D.boundary(2)) == 40 and len(D.boundary(-1)) == 24
+    for idx in (0, 1, 2, -1):
+        assert D.signed_area2(D.boundary(idx)) < 0          # clockwise, like every domain the reference uses
+    with pytest.raises(ValueError):
+        D.boundary(7)
+    for seed in range(20):
+        pts = D.random_domain(seed)
+        assert len(pts) >= 8 and D.signed_area2(pts) < 0
+        assert all(round(x, 4) == x and round(y, 4) == y for x, y in pts)
+        assert pts == D.random_domain(seed)                # deterministic
+        assert all(pts[i] != pts[i - 1] for i in range(len(pts)))
+
+
+def test_read_polygon_format(tmp_path):
+    from reinforcementlearning4meshgeneration_amd.domains import read_polygon
+    f = tmp_path / "d.json"
+    f.write_text("[[100, 200], [150.5, 200], [150, 100]]\n[[0,0]]\n")     # only the first line counts
+    assert read_polygon(f) == [(1.0, 2.0), (1.505, 2.0), (1.5, 1.0)]
+
+
+def test_spaces_and_sharding():
+    from reinforcementlearning4meshgeneration_amd import sharding
+    from reinforcementlearning4meshgeneration_amd.vec_env import ACTION_HIGH, ACTION_LOW, make_spaces
+    obs_space, act_space = make_spaces()
+    assert obs_space.shape == (18,) and act_space.shape == (3,)
+    assert np.allclose(act_space.low, [-1, -1.5, 0]) and np.allclose(act_space.high, [1, 1.5, 1.5])
+    assert float(obs_space.low.min()) == -999 and float(obs_space.high.max()) == 999
+    a = act_space.sample()
+    assert a.dtype == np.float32 and np.all(a >= ACTION_LOW) and np.all(a <= ACTION_HIGH)
+    for n, w in ((4096, 8), (10, 3), (7, 8), (32768, 8)):
+        blocks = [sharding.shard_range(n, w, r) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in blocks]
+        assert max(sizes) - min(sizes) <= 1
