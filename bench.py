@@ -35,6 +35,24 @@ def algorithmic_bytes(steps, valid, sum_ring, sum_ring_valid):
     return 28 * sum_ring + 158 * steps + 28 * sum_ring_valid + 48 * valid
 
 
+def pmc_traffic(n_envs):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/): FETCH_SIZE and
+    WRITE_SIZE are collected in separate --pmc runs, in KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950.  None when no profile of this workload is committed (bench.py cannot run the profiler on itself)."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("_summary.json"):
+                try:
+                    d = json.load(open(os.path.join(pdir, f)))
+                    if d.get("bench_line_under_rocprof", {}).get("config", {}).get("n_envs_per_gpu") == n_envs:
+                        best = (d["hbm_traffic_bytes_per_launch"]["gfx950_corrected_(2*FETCH+WRITE)*1024"], "profiles/" + f)
+                except Exception:
+                    pass
+    return best if best else (None, None)
+
+
 def cpu_baseline(n_envs, seed, budget_s=12.0):
     """The CPU oracle (oracle/meshenv_ref.c, plain C, host libm) on the same workload, bounded sample."""
     from oracle.ref_lib import RefBatch, RefEnv
@@ -165,8 +183,9 @@ def main():
         alg = algorithmic_bytes(d["steps"], d["valid"], d["sum_ring"], d["sum_ring_valid"]) / K
         avg_ms = float(np.mean(kt))
         achieved = alg / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(n)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "kernel": "meshenv::k_step", "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": float(np.min(kt)) * 1e3,
                            "algorithmic_bytes_per_launch": alg, "launches_timed": int(len(kt))}
     env.close()
