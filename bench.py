@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--time-every", type=int, default=8, help="HIP-event-time every k-th launch of the timed region")
     args = ap.parse_args()
 
     import torch
@@ -141,7 +142,7 @@ def main():
     torch.cuda.synchronize()
     c0 = env.counters()
     if not args.no_kernel_timing:
-        env.set_timing(True)
+        env.set_timing(args.time_every)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -157,7 +158,7 @@ def main():
     kt = None
     if not args.no_kernel_timing:
         kt = env.kernel_times_ms()
-        env.set_timing(False)
+        env.set_timing(0)
     c1 = env.counters()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -178,8 +178,10 @@ int meshenv_counters(MeshEnv *h, uint64_t *out_host);
 
 /*
  * Per-launch kernel timing with HIP events recorded on the handle's stream around every
- * meshenv_step / meshenv_rollout launch (bench.py's roofline figure).  meshenv_set_timing(h, 1)
- * arms a pool of MESHENV_TIMING_POOL event pairs and clears the record; meshenv_kernel_times()
+ * meshenv_step / meshenv_rollout launch (bench.py's roofline figure).  meshenv_set_timing(h, k)
+ * with k > 0 times every k-th launch (an event pair costs ~8 us of stream time per launch on this stack, so
+ * k = 1 slows a launch-bound loop down; bench.py samples), k = 0 switches timing off.  Arming creates
+ * a pool of MESHENV_TIMING_POOL event pairs and clears the record; meshenv_kernel_times()
  * synchronises and copies the durations (milliseconds, launch order) of the launches recorded since
  * then -- at most the newest MESHENV_TIMING_POOL of them -- into ms_host[cap] and clears the record.
  */

@@ -36,12 +36,11 @@ __device__ __forceinline__ P2 mkp(double x, double y)
 __device__ MESHENV_NOINLINE double div1e4_slow(double r) { return r / 1e4; }
 __device__ __forceinline__ double div1e4(double r)
 {
-    if (r < 8589934592.0) {
-        const double q0 = r * 1e-4;
-        const double rem = fma(-q0, 1e4, r);
-        return fma(rem, 1e-4, q0);
-    }
-    return div1e4_slow(r);
+    const double q0 = r * 1e-4;
+    const double rem = fma(-q0, 1e4, r);
+    double q = fma(rem, 1e-4, q0);
+    if (__builtin_expect(!(r < 8589934592.0), 0)) q = div1e4_slow(r);  // never taken for coordinates / angles
+    return q;
 }
 
 // Python's round(float, 4): correctly rounded decimal rounding of the exact binary value, ties to even.
@@ -50,17 +49,17 @@ __device__ __forceinline__ double div1e4(double r)
 // to the decimal r*1e-4, which is what CPython's dtoa/strtod round trip returns.
 __device__ __forceinline__ double round4_py(double x)
 {
+    // written with selects only: the lanes of a wave take different rounding directions
     const double ax = fabs(x);
     const double y = ax * 1e4;
-    if (!(y < 4503599627370496.0)) return x;  // also NaN/inf
     const double e = fma(ax, 1e4, -y);
     const double f = floor(y);
     const double t = (y - f) - 0.5;
     const double s = t + e;
-    double r = f;
-    if (s > 0.0) r = f + 1.0;
-    else if (s == 0.0 && (((long long)f) & 1LL)) r = f + 1.0;
-    return copysign(div1e4(r), x);
+    const bool up = (s > 0.0) || (s == 0.0 && ((((long long)f) & 1LL) != 0));
+    const double r = up ? f + 1.0 : f;
+    const double q = copysign(div1e4(r), x);
+    return (y < 4503599627370496.0) ? q : x;  // huge / inf / NaN pass through
 }
 
 // round(np.float64, 4): numpy's multiply / rint / divide
@@ -111,7 +110,7 @@ __device__ __forceinline__ void cw_terms(P2 s, P2 p1, P2 p2, double &c, double &
 __device__ __forceinline__ double cw_finish(double t)
 {
     const double theta = -t;
-    return signbit(theta) ? round4_py(2 * kPi + theta) : round4_py(theta);
+    return round4_py(signbit(theta) ? 2 * kPi + theta : theta);
 }
 
 // Vertex.to_find_clockwise_angle, C:91-100
@@ -132,9 +131,12 @@ __device__ __forceinline__ double cw(P2 s, P2 p1, P2 p2)
 //    the four sign cases below reduces "a in {0, 3.1416, 6.2832}" to one comparison of |r| against the matching
 //    rounding boundary.  Within 1e-8 of a boundary (and for d == 0, which implies c == 0) the reference
 //    evaluation (atan2, round, sin, round) is used, so the result is the reference's in every case.
-__device__ __forceinline__ bool sin_rounds_to_zero_exact(double c, double d)
+// (out of line: the rare guard-band / degenerate path; keeping it out of straddle() leaves straddle a leaf that
+// inlines into the kernels -- as a non-leaf function it saved its return address through a scratch-memory spill,
+// a full memory round trip per call)
+__device__ MESHENV_NOINLINE bool sin_rounds_to_zero_exact(double c, double d)
 {
-    return round4_py(sin_nc(cw_finish(atan2_nc(c, d)))) == 0.0;
+    return round4_py(sin(cw_finish(atan2(c, d)))) == 0.0;
 }
 
 __device__ __forceinline__ bool sin_rounds_to_zero(double c, double d)
@@ -163,7 +165,7 @@ __device__ __forceinline__ bool sin_rounds_to_zero(double c, double d)
 __device__ __forceinline__ double crossp(double ax, double ay, double bx, double by) { return ax * by - bx * ay; }
 
 // Segment.straddle, C:491-516; self = (p1,p2), another = (q1,q2)
-__device__ MESHENV_NOINLINE bool straddle(P2 p1, P2 p2, P2 q1, P2 q2)
+__device__ __forceinline__ bool straddle(P2 p1, P2 p2, P2 q1, P2 q2)
 {
     double c1, d1, c2, d2;
     cw_terms(p1, q1, p2, c1, d1);
@@ -355,15 +357,13 @@ __device__ __forceinline__ double round4_py_scaled(double x)
 {
     const double ax = fabs(x);
     const double y = ax * 1e4;
-    if (!(y < 4503599627370496.0)) return x;
     const double e = fma(ax, 1e4, -y);
     const double f = floor(y);
     const double t = (y - f) - 0.5;
     const double s = t + e;
-    double r = f;
-    if (s > 0.0) r = f + 1.0;
-    else if (s == 0.0 && (((long long)f) & 1LL)) r = f + 1.0;
-    return copysign(r, x);
+    const bool up = (s > 0.0) || (s == 0.0 && ((((long long)f) & 1LL) != 0));
+    const double r = copysign(up ? f + 1.0 : f, x);
+    return (y < 4503599627370496.0) ? r : x;
 }
 __device__ __forceinline__ double round4_np_scaled(double x) { return rint(x * 1e4); }
 

@@ -30,7 +30,8 @@ struct MeshEnv {
     std::vector<int32_t> dom_off_host, env_dom_host;
     std::vector<void *> allocs;
     std::string err;
-    bool timing = false;
+    int timing = 0;              // 0 = off, k = record every k-th launch
+    long long launch_count = 0;
     std::vector<hipEvent_t> ev;  // 2 * MESHENV_TIMING_POOL events, created on first use
     long long ev_count = 0;      // launches recorded since timing was armed
 };
@@ -288,7 +289,8 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
     if (!actions_dev || !obs_dev || !reward_dev || !done_dev || !complete_dev) return fail_arg(h, "meshenv_step: null device pointer");
     if (n_steps <= 0) return fail_arg(h, "meshenv_rollout: n_steps must be positive");
     const size_t slot = (size_t)(h->ev_count % MESHENV_TIMING_POOL);
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2 * slot], h->stream));
+    const bool timed = h->timing > 0 && (h->launch_count++ % h->timing) == 0;
+    if (timed) HIP_TRY(h, hipEventRecord(h->ev[2 * slot], h->stream));
     if (n_steps == 1)
         hipLaunchKernelGGL(k_step<false>, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, 1, actions_dev, obs_dev,
                            reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
@@ -296,7 +298,7 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         hipLaunchKernelGGL(k_step<true>, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, n_steps, actions_dev, obs_dev,
                            reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
     HIP_TRY(h, hipGetLastError());
-    if (h->timing) {
+    if (timed) {
         HIP_TRY(h, hipEventRecord(h->ev[2 * slot + 1], h->stream));
         h->ev_count += 1;
     }
@@ -499,7 +501,8 @@ int meshenv_set_timing(MeshEnv *h, int enable)
         h->ev.resize(2 * (size_t)MESHENV_TIMING_POOL, nullptr);
         for (hipEvent_t &e : h->ev) HIP_TRY(h, hipEventCreate(&e));
     }
-    h->timing = enable != 0;
+    h->timing = enable > 0 ? enable : 0;
+    h->launch_count = 0;
     h->ev_count = 0;
     return MESHENV_OK;
 }

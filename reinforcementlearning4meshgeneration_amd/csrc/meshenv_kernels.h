@@ -234,31 +234,38 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     //      rows (lane 0 -> rotation_angle, lane 3 -> theta), lane 6 the action frame (D:69).
     //   neighbour lane j < 3 : right side i = j     -> vertex idx-1-j
     //   neighbour lane j >= 3: left side  i = j - 3 -> vertex idx+1+(j-3)
+    // Index selection is select-only (no lane-divergent branches): every lane evaluates one dist() and one set
+    // of atan2 terms, lanes without a job use slot 0 / a dummy argument.
+    const int nbr = lane < 3 ? wrapi(idc - 1 - lane, n) : wrapi(idc + 1 + (lane - 3), n);  // valid for lane < 6
+    const int nbr16 = (lane - 16) < 3 ? wrapi(idc - 1 - (lane - 16), n) : wrapi(idc + 1 + (lane - 19), n);
+    const int bqa = bq.a, bqlo = bq.a < bq.b ? bq.a : bq.b;
     int ia = 0, ib = 0;
-    bool dj = false;
-    if (lane < 6) { ia = wrapi(idc + 2 - lane, n); ib = wrapi(idc + 3 - lane, n); dj = true; }
-    else if (lane >= 16 && lane < 22) {
-        const int j = lane - 16;
-        ia = idc; ib = j < 3 ? wrapi(idc - 1 - j, n) : wrapi(idc + 1 + (j - 3), n); dj = true;
-    } else if (bq.mode == 1) {
-        if (lane == 8) { ia = bq.a; ib = wrapi(bq.a + 1, n); dj = true; }
-        else if (lane == 9) { ia = bq.a; ib = wrapi(bq.a - 1, n); dj = true; }
-        else if (lane >= 10 && lane < 14) { ia = wrapi(bq.a - 2 + (lane - 10), n); ib = wrapi(bq.a - 1 + (lane - 10), n); dj = true; }
-    } else if (bq.mode == 2) {
-        const int lo = bq.a < bq.b ? bq.a : bq.b;
-        if (lane == 8) { ia = bq.a; ib = bq.b; dj = true; }
-        else if (lane >= 10 && lane < 15) { ia = wrapi(lo - 2 + (lane - 10), n); ib = wrapi(lo - 1 + (lane - 10), n); dj = true; }
+    {
+        const bool j0 = lane < 6, j16 = lane >= 16 && lane < 22;
+        const bool m1 = bq.mode == 1, m2 = bq.mode == 2;
+        const int k = lane - 10;
+        const bool jwin = lane >= 10 && lane < (m1 ? 14 : 15) && (m1 || m2);
+        const int wbase = m1 ? bqa : bqlo;
+        ia = j0 ? wrapi(idc + 2 - lane, n) : ia;
+        ib = j0 ? wrapi(idc + 3 - lane, n) : ib;
+        ia = j16 ? idc : ia;
+        ib = j16 ? nbr16 : ib;
+        ia = jwin ? wrapi(wbase - 2 + k, n) : ia;
+        ib = jwin ? wrapi(wbase - 1 + k, n) : ib;
+        ia = (lane == 8 || lane == 9) && (m1 || m2) ? bqa : ia;
+        ib = lane == 8 ? (m1 ? wrapi(bqa + 1, n) : (m2 ? bq.b : ib)) : ib;
+        ib = (lane == 9 && m1) ? wrapi(bqa - 1, n) : ib;
     }
-    double dv = 0.0;
-    if (dj) dv = dist(ldp(c, ia), ldp(c, ib));
-    double jy = 0.0, jx = 1.0;
-    if (lane < 6) {
-        const int vi = lane < 3 ? wrapi(idc - 1 - lane, n) : wrapi(idc + 1 + (lane - 3), n);
-        if (lane == 0) cw_terms(ref, right, mkp(ref.x + 1, ref.y), jy, jx);
-        else cw_terms(ref, ldp(c, vi), right, jy, jx);
-    } else if (lane == 6) {
-        jy = right.y - ref.y;
-        jx = right.x - ref.x;
+    const double dv = dist(ldp(c, ia), ldp(c, ib));
+    double jy, jx;
+    {
+        // lanes 1..5: cw(ref; v, right); lane 0: cw(ref; right, ref + (1, 0)); lane 6: atan2(right - ref)
+        const P2 v = ldp(c, lane < 6 ? nbr : 0);
+        const P2 p1 = lane == 0 ? right : v;
+        const P2 p2 = lane == 0 ? mkp(ref.x + 1, ref.y) : right;
+        cw_terms(ref, p1, p2, jy, jx);
+        jy = lane == 6 ? right.y - ref.y : jy;
+        jx = lane == 6 ? right.x - ref.x : jx;
     }
     double jt = 0.0;
     if (lane < 7) jt = atan2_nc(jy, jx);
@@ -290,7 +297,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     // ---- stage B: sincos jobs: lane 0 theta/2, lane 1 rotation_angle, lane 2 action frame,
     //      lanes 3, 4 the two quad corners of Mesh.compute_area
     double sj = 0.0, cj = 1.0;
-    if (lane < 5) {
+    if (lane < 5) {  // one exec-masked call; the argument is a select chain
         const double arg = lane == 0 ? theta / 2 : lane == 1 ? rot : lane == 2 ? thd : lane == 3 ? bq.q_ang0 : bq.q_ang2;
         const SinCos sc = sincos_nc(arg);
         sj = sc.s;
@@ -367,23 +374,19 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
                 else if (k == 1) k1 = key < k1 ? key : k1;
                 else k2 = key < k2 ? key : k2;
             }
-            // Segment(ref, p_s).intersection_vertex(Segment(ring[i], ring[i+1])), C:649-668
+            // Segment(ref, p_s).intersection_vertex(Segment(ring[i], ring[i+1])), C:649-668.  The three branches of
+            // the reference (w.y == 0 / w.x == 0 / general) are one instruction stream with selected operands, so an
+            // axis-aligned domain does not pay for all three in turn:  s = num / den,  h = (a + s * b) / cden
             const P2 b = ldp(c, wrapi(ii + 1, n));
             const double wx = b.x - v.x, wy = b.y - v.y;
-            double s = 0.0, h = 0.0;
-            bool have = true;
-            if (wy == 0.0) {
-                have = uy != 0.0;
-                s = (v.y - ref.y) / uy;
-                h = (ref.x - v.x + s * ux) / wx;
-            } else if (wx == 0.0) {
-                have = ux != 0.0;
-                s = (v.x - ref.x) / ux;
-                h = (ref.y - v.y + s * uy) / wy;
-            } else {
-                s = ((ref.x - v.x) / wx - (ref.y - v.y) / wy) / (uy / wy - ux / wx);
-                h = (ref.x - v.x + s * ux) / wx;
-            }
+            const bool hy = wy == 0.0, hx = !hy && wx == 0.0;
+            const double rx = ref.x - v.x, ry = ref.y - v.y;
+            const double num_g = rx / wx - ry / wy, den_g = uy / wy - ux / wx;
+            const double num = hy ? (v.y - ref.y) : (hx ? (v.x - ref.x) : num_g);
+            const double den = hy ? uy : (hx ? ux : den_g);
+            const bool have = !((hy && uy == 0.0) || (hx && ux == 0.0));
+            const double s = num / den;
+            const double h = hx ? (ry + s * uy) / wy : (rx + s * ux) / wx;
             if (have && 0.0 < s && s < 1.0 && 0.0 < h && h < 1.0) {
                 const double val = (dist(ref, mkp(ref.x + s * ux, ref.y + s * uy)) / radius) / bl;
                 if (val < rbest) { rbest = val; rord = ord; }
@@ -520,10 +523,12 @@ struct VRing {
 
 __device__ __forceinline__ P2 vr_at(const Ctx &c, const VRing &r, int j)
 {
-    if (r.is_new) return j == r.lo ? r.new_point : ldp(c, j);
-    int o = j + (j >= r.lo ? 1 : 0);
-    o += (o >= r.hi ? 1 : 0);
-    return ldp(c, o);
+    // select-only: the slot index is remapped for the removal rules, the new vertex is patched in afterwards
+    int o = j + ((!r.is_new && j >= r.lo) ? 1 : 0);
+    o += (!r.is_new && o >= r.hi) ? 1 : 0;
+    const P2 p = ldp(c, o);
+    const bool patch = r.is_new && j == r.lo;
+    return mkp(patch ? r.new_point.x : p.x, patch ? r.new_point.y : p.y);
 }
 
 // Mesh.is_valid(0), C:730-749 + segments_crossed C:806-818, plus every other evaluation that only depends on
@@ -540,6 +545,15 @@ __device__ __forceinline__ bool quad_pass(Ctx &c, const Params &prm, const VRing
 {
     const int lane = c.lane;
     const double2 *q = c.sc->q;
+    // (0) exact early reject.  Corner angle a = cw(m_i; m_i+1, m_i-1) with atan2 terms (cc, dd): cc > 0 gives
+    //     theta = -atan2 < 0 -> a = round(2pi + theta) >= pi; cc == +-0 gives a in {0, pi, 2pi} (all rounded): every
+    //     case violates 0.01pi <= a <= 0.99pi, so only cc < 0 can pass Mesh.is_valid -- no atan2 needed to fail.
+    double qy = -1.0, qx = 1.0;
+    if (lane < 4) {
+        const double2 a = q[lane], b = q[(lane + 1) & 3], d = q[(lane + 3) & 3];
+        cw_terms(mkp(a.x, a.y), mkp(b.x, b.y), mkp(d.x, d.y), qy, qx);
+    }
+    if (__ballot(!(qy < 0.0)) != 0ULL && prm.min_degree > 0.0 && prm.max_degree < kPi) return false;
     // (a) segments_crossed: is_cross(m0m1, m2m3) || is_cross(m0m3, m1m2); 4 independent straddles
     bool sres = false;
     if (lane < 4) {
@@ -558,18 +572,21 @@ __device__ __forceinline__ bool quad_pass(Ctx &c, const Params &prm, const VRing
         const int a = (0x103210 >> (4 * lane)) & 3, b = (0x322103 >> (4 * lane)) & 3;
         c.sc->tmp2[lane] = dist(mkp(q[a].x, q[a].y), mkp(q[b].x, q[b].y));
     }
-    // (c) atan2 jobs
-    double jy = 0.0, jx = 1.0;
-    if (lane < 4) {
-        const double2 a = q[lane], b = q[(lane + 1) & 3], d = q[(lane + 3) & 3];
-        cw_terms(mkp(a.x, a.y), mkp(b.x, b.y), mkp(d.x, d.y), jy, jx);
-    } else if (lane < 12) {
-        const int k = (lane - 4) >> 1, o = ((lane - 4) & 1) + 1;
+    // (c) atan2 jobs: lanes 0..3 reuse the corner terms of (0); lanes 4..13 address the post-update ring
+    double jy = qy, jx = qx;
+    {
+        const int j = lane - 4;
+        const int k = j >> 1, o = (j & 1) + 1;
         const int pos = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
-        cw_terms(vr_at(c, vr, pos), vr_at(c, vr, wrapi(pos + o, vr.n)), vr_at(c, vr, wrapi(pos - o, vr.n)), jy, jx);
-    } else if (lane < 14) {
-        const int ctr = lane == 12 ? bc0 : bc1;
-        cw_terms(vr_at(c, vr, ctr), vr_at(c, vr, wrapi(ctr + 1, vr.n)), vr_at(c, vr, wrapi(ctr - 1, vr.n)), jy, jx);
+        const bool keyjob = lane >= 4 && lane < 12, bqjob = lane == 12 || lane == 13;
+        const int ctr = keyjob ? pos : (lane == 12 ? bc0 : bc1);
+        const int off = keyjob ? o : 1;
+        const bool job = keyjob || bqjob;
+        const int ci = job ? ctr : 0, i1 = job ? wrapi(ctr + off, vr.n) : 0, i2 = job ? wrapi(ctr - off, vr.n) : 0;
+        double ty, tx;
+        cw_terms(vr_at(c, vr, ci), vr_at(c, vr, i1), vr_at(c, vr, i2), ty, tx);
+        jy = job ? ty : jy;
+        jx = job ? tx : jx;
     }
     bool bad = false;
     if (lane < 14) {
@@ -1011,6 +1028,9 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifndef MESHENV_STAMPS
+    const EnvCounters cnt0 = S.cnt[env];  // requested with the rest of the state: no round trip at the end
+#endif
     load_env(c, S, env);
 #ifdef MESHENV_STAMPS
     const unsigned long long stamp_t1 = __builtin_amdgcn_s_memrealtime();
@@ -1054,7 +1074,7 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     if (c.lane < 16) S.dbg[(size_t)env * 16 + c.lane] = c.sc->stamps[c.lane];
 #else
     if (c.lane == 0) {
-        EnvCounters k = S.cnt[env];
+        EnvCounters k = cnt0;
         k.steps += (unsigned long long)T; k.valid += st_valid; k.sum_n += st_sum; k.sum_n_valid += st_sumv;
         S.cnt[env] = k;
     }

@@ -250,8 +250,9 @@ class MeshVecEnv:
         self._check(self._L.meshenv_counters(self._handle, out), "meshenv_counters")
         return dict(steps=int(out[0]), valid=int(out[1]), sum_ring=int(out[2]), sum_ring_valid=int(out[3]))
 
-    def set_timing(self, enable: bool):
-        self._check(self._L.meshenv_set_timing(self._handle, 1 if enable else 0), "meshenv_set_timing")
+    def set_timing(self, every: int):
+        """Time every `every`-th step/rollout launch with HIP events (0 / False = off)."""
+        self._check(self._L.meshenv_set_timing(self._handle, int(every)), "meshenv_set_timing")
 
     def kernel_times_ms(self) -> np.ndarray:
         """Durations (ms) of the step/rollout launches recorded since set_timing(True) / the last call."""

@@ -12,7 +12,7 @@ def run(name, doms, a0_mode):
     if a0_mode is not None: a[:,:,0]=a0_mode
     a=a.contiguous()
     for t in range(20): env.step(a[t])
-    torch.cuda.synchronize(); c0=env.counters(); env.set_timing(True)
+    torch.cuda.synchronize(); c0=env.counters(); env.set_timing(1)
     for t in range(20,T): env.step(a[t])
     kt=env.kernel_times_ms(); c1=env.counters()
     st=c1['steps']-c0['steps']; v=c1['valid']-c0['valid']
