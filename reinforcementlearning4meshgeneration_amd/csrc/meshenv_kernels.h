@@ -257,10 +257,16 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         ib = (lane == 9 && m1) ? wrapi(bqa - 1, n) : ib;
     }
     const double dv = dist(ldp(c, ia), ldp(c, ib));
+    // atan2 jobs.  lanes 1..5: cw(ref; v, right); lane 0: cw(ref; right, ref + (1, 0)); lane 6: atan2(right - ref);
+    // lanes 7..63: the clockwise angle of traversal position ord = lane - 7 of the observation scan (stage C only
+    // evaluates atan2 itself for rings longer than 58), so stages A and C share one transcendental pass.
+    constexpr int kScanLanes = 57;
+    const int ord_a = lane - 7;
+    const bool scanjob = lane >= 7 && ord_a < n - 1;
     double jy, jx;
     {
-        // lanes 1..5: cw(ref; v, right); lane 0: cw(ref; right, ref + (1, 0)); lane 6: atan2(right - ref)
-        const P2 v = ldp(c, lane < 6 ? nbr : 0);
+        const int vsel = lane < 6 ? nbr : (scanjob ? wrapi(idc - 1 - ord_a, n) : 0);
+        const P2 v = ldp(c, vsel);
         const P2 p1 = lane == 0 ? right : v;
         const P2 p2 = lane == 0 ? mkp(ref.x + 1, ref.y) : right;
         cw_terms(ref, p1, p2, jy, jx);
@@ -268,8 +274,9 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         jx = lane == 6 ? right.x - ref.x : jx;
     }
     double jt = 0.0;
-    if (lane < 7) jt = atan2_nc(jy, jx);
+    if (lane < 7 || scanjob) jt = atan2_nc(jy, jx);
     const double na = cw_finish(jt);
+    if (scanjob) c.ang_ord[ord_a] = na;
     // base_length = round(sum of the 6 window edges / 6, 4), summed in the reference's order
     double sum = lane_f64(dv, 0);
     sum += lane_f64(dv, 1);
@@ -315,6 +322,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     const double qy = (0.0 + sr * px) + cr * py;
     const double ux = uniform_f64((ref.x + qx) - ref.x), uy = uniform_f64((ref.y + qy) - ref.y);  // u = p_s - ref
     MESHENV_STAMP(c, 11);
+    __syncthreads();
 
     // ---- stage C: O(n) scan, traversal order ord = 0..n-2 <-> ring index idx-1-ord (C:1239-1267), fused with the
     //      near-vertex scan of compute_boundary_quality (ring index = base + lane)
@@ -334,12 +342,16 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         const bool in_range = ord < n - 1;
         const int ii = wrapi(idc - 1 - (in_range ? ord : 0), n);
         const P2 v = ldp(c, ii);
-        double cc = 0.0, dd = 1.0;
-        if (in_range) cw_terms(ref, v, right, cc, dd);
+        const bool calc = in_range && ord >= kScanLanes;  // positions stage A had no lane for
         double t = 0.0;
-        if (in_range) t = atan2_nc(cc, dd);
-        const double angle = cw_finish(t);
-        if (in_range) c.ang_ord[ord] = angle;
+        if (calc) {
+            double cc, dd;
+            cw_terms(ref, v, right, cc, dd);
+            t = atan2_nc(cc, dd);
+        }
+        double angle = cw_finish(t);
+        if (calc) c.ang_ord[ord] = angle;
+        else if (in_range) angle = c.ang_ord[ord];
         // (2) boundary-quality scan (mode 1): added(i) = near(i) && !added(i-1), M:355-357
         if (bq.mode == 1) {
             const int i = base + lane;
@@ -469,9 +481,9 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     }
 }
 
-// ------------------------------------------------------------------------------------------ point in polygon (a7)
+// ------------------------------------------------------------------------------------------ ring passes of the checks (a7, a8, a10 filter)
 
-// is_point_inside_area -> calculate_crossing_segments, M:539-546, 47-102.  One ring edge per lane.
+// is_point_inside_area -> calculate_crossing_segments, M:539-546, 47-102.  One ring edge per lane, ballot parity.
 // Orientation tests only use sign and zero-ness of round(dy, 4), so the scaled roundings are used.
 __device__ __forceinline__ bool point_inside(const Ctx &c, const Params &prm, P2 p)
 {
@@ -480,33 +492,65 @@ __device__ __forceinline__ bool point_inside(const Ctx &c, const Params &prm, P2
     int parity = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + c.lane;
+        const bool in = i < n;
+        const int ic = in ? i : 0;
+        const int im1 = wrapi(ic - 1, n);
+        const P2 vi = ldp(c, ic), vm = ldp(c, im1);
+        const bool np_i = (c.id[ic] & kNewBit) != 0, np_m = (c.id[im1] & kNewBit) != 0;
+        const double dy = vi.y - vm.y;
+        const double orientation = (np_i || np_m) ? round4_np_scaled(dy) : round4_py_scaled(dy);
         bool counted = false;
-        if (i < n) {
-            const int im1 = wrapi(i - 1, n);
-            const P2 vi = ldp(c, i), vm = ldp(c, im1);
-            const bool np_i = (c.id[i] & kNewBit) != 0, np_m = (c.id[im1] & kNewBit) != 0;
-            const double dy = vi.y - vm.y;
-            const double orientation = (np_i || np_m) ? round4_np_scaled(dy) : round4_py_scaled(dy);
-            // is_cross is a pure conjunction; the ray-side test is the selective one, so it goes first
-            if (orientation != 0.0 && straddle(p, far, vi, vm) && straddle(vi, vm, p, far)) {
-                if (round4_np_scaled(vi.y - p.y) == 0.0) {
-                    const int ip1 = wrapi(i + 1, n);
-                    const double dyn = ldp(c, ip1).y - vi.y;
-                    const double next_o = ((c.id[ip1] & kNewBit) != 0 || np_i) ? round4_np_scaled(dyn) : round4_py_scaled(dyn);
-                    counted = next_o != 0.0 && !(next_o * orientation < 0.0) && orientation < 0.0;
-                } else if (round4_np_scaled(vm.y - p.y) == 0.0) {
-                    const int im2 = wrapi(i - 2, n);
-                    const double dyp = vm.y - ldp(c, im2).y;
-                    const double pre_o = (np_m || (c.id[im2] & kNewBit) != 0) ? round4_np_scaled(dyp) : round4_py_scaled(dyp);
-                    counted = pre_o != 0.0 && !(pre_o * orientation < 0.0) && !(orientation < 0.0);
-                } else {
-                    counted = true;
-                }
-            }
+        // is_cross is a pure conjunction; the ray-side test is the selective one, so it goes first
+        if (in && orientation != 0.0 && straddle(p, far, vi, vm) && straddle(vi, vm, p, far)) {
+            const bool on_i = round4_np_scaled(vi.y - p.y) == 0.0, on_m = round4_np_scaled(vm.y - p.y) == 0.0;
+            // neighbour edge: the next one when the ray passes through vertex i, the previous one when through i-1
+            const int ia = on_i ? wrapi(ic + 1, n) : im1, ib = on_i ? ic : wrapi(ic - 2, n);
+            const double dyo = ldp(c, ia).y - ldp(c, ib).y;
+            const double other = ((c.id[ia] & kNewBit) != 0 || (c.id[ib] & kNewBit) != 0) ? round4_np_scaled(dyo) : round4_py_scaled(dyo);
+            const bool keep = other != 0.0 && !(other * orientation < 0.0);
+            counted = on_i ? (keep && orientation < 0.0) : (on_m ? (keep && !(orientation < 0.0)) : true);
         }
         parity ^= __popcll(__ballot(counted)) & 1;
     }
     return parity != 0;
+}
+
+// distance filter of check_intersection_with_boundary (M:511-513): ring vertices outside the quad that are
+// nearer to the reference vertex than the farthest quad vertex
+struct NearFilter {
+    P2 ref;
+    double max_dist;
+    int mp0, mp1, mp2, mp3;  // ring slots of the quad vertices (-1: not on the ring)
+};
+
+__device__ __forceinline__ bool nf_near(const NearFilter &f, int i, P2 v)
+{
+    return !(i == f.mp0 || i == f.mp1 || i == f.mp2 || i == f.mp3) && dist(f.ref, v) < f.max_dist;
+}
+
+// survivors of one 64-vertex chunk go to the LDS list, in ring order
+__device__ __forceinline__ int nf_compact(Ctx &c, bool near, int i, int count)
+{
+    const unsigned long long m = __ballot(near);
+    if (near) c.list[count + __popcll(m & ((1ULL << c.lane) - 1ULL))] = i;
+    return count + __popcll(m);
+}
+
+// One pass over the ring vertices: the distance filter (list in LDS, returns its length) and, for a rule-0
+// candidate point p (same_eps > 0), find_same_point (B:599-602; only existence is used).
+__device__ __forceinline__ int near_filter_pass(Ctx &c, const NearFilter &f, P2 p, double same_eps, bool &same)
+{
+    int count = 0;
+    bool any_same = false;
+    for (int i0 = 0; i0 < c.n; i0 += 64) {
+        const int i = i0 + c.lane;
+        const bool in = i < c.n;
+        const P2 v = ldp(c, in ? i : 0);
+        if (same_eps > 0.0) any_same = any_same || (__ballot(in && dist(v, p) < same_eps) != 0ULL);
+        count = nf_compact(c, in && nf_near(f, i, v), i, count);
+    }
+    same = any_same;
+    return count;
 }
 
 // ------------------------------------------------------------------------------------------ quad pass (a9 + speculative a5/a12 jobs)
@@ -603,33 +647,15 @@ __device__ __forceinline__ bool quad_pass(Ctx &c, const Params &prm, const VRing
     return !any_bad;
 }
 
-// check_intersection_with_boundary, M:510-530.  mp* = ring slots of the quad vertices (-1 = new vertex),
-// r = position of the reference vertex in the quad.  Pass 1: one ring vertex per lane, distance filter,
-// survivors compacted into an LDS list.  Pass 2: one (vertex, quad edge, ring neighbour) test per lane.
-__device__ __forceinline__ bool intersects_boundary(Ctx &c, int mp0, int mp1, int mp2, int mp3, int r)
+// check_intersection_with_boundary, M:510-530, after the distance filter: `count` surviving ring vertices are in
+// c.list; one (vertex, quad edge, ring neighbour) segment test per lane.  r = position of the reference vertex in
+// the quad (c.sc->q).
+__device__ __forceinline__ bool cross_jobs(Ctx &c, int count, int mp0, int mp1, int mp2, int mp3, int r)
 {
-    const int n = c.n, lane = c.lane;
-    const double2 *q = c.sc->q;
-    const P2 ref = mkp(q[r].x, q[r].y);
-    double max_dist = -1.0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (k != r) {
-            const double d = dist(ref, mkp(q[k].x, q[k].y));
-            max_dist = d > max_dist ? d : max_dist;
-        }
-    }
-    int count = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        bool near = false;
-        if (i < n && !(i == mp0 || i == mp1 || i == mp2 || i == mp3)) near = dist(ref, ldp(c, i)) < max_dist;
-        const unsigned long long m = __ballot(near);
-        if (near) c.list[count + __popcll(m & ((1ULL << lane) - 1ULL))] = i;
-        count += __popcll(m);
-    }
     if (count == 0) return false;
+    const int n = c.n, lane = c.lane;
     __syncthreads();
+    const double2 *q = c.sc->q;
     const double2 qa = q[(r + 3) & 3], qb = q[(r + 2) & 3], qc = q[(r + 1) & 3];
     const P2 c0a = mkp(qa.x, qa.y), c0b = mkp(qb.x, qb.y);  // (m[r-1], m[r-2])
     const P2 c1b = mkp(qc.x, qc.y);                          // (m[r-2], m[r-3])
@@ -637,19 +663,26 @@ __device__ __forceinline__ bool intersects_boundary(Ctx &c, int mp0, int mp1, in
     const int total = 4 * count;
     for (int j0 = 0; j0 < total && !any_hit; j0 += 64) {
         const int j = j0 + lane;
-        bool hit = false;
-        if (j < total) {
-            const int i = c.list[j >> 2];
-            const int nb = (j & 2) ? wrapi(i + 1, n) : wrapi(i - 1, n);
-            if (!(nb == mp0 || nb == mp1 || nb == mp2 || nb == mp3)) {
-                const P2 ea = (j & 1) ? c0b : c0a, eb = (j & 1) ? c1b : c0b;
-                hit = is_cross(ea, eb, ldp(c, i), ldp(c, nb));
-            }
-        }
+        const bool in = j < total;
+        const int i = c.list[in ? (j >> 2) : 0];
+        const int nb = (j & 2) ? wrapi(i + 1, n) : wrapi(i - 1, n);
+        const bool use = in && !(nb == mp0 || nb == mp1 || nb == mp2 || nb == mp3);
+        const P2 ea = (j & 1) ? c0b : c0a, eb = (j & 1) ? c1b : c0b;
+        const bool hit = use && is_cross(ea, eb, ldp(c, i), ldp(c, nb));
         any_hit = __ballot(hit) != 0ULL;
     }
     __syncthreads();
     return any_hit;
+}
+
+// max distance from the reference vertex to the other quad vertices (M:510), quad given as four points
+__device__ __forceinline__ double quad_max_dist(int lane, P2 ref, P2 a, P2 b, P2 cpt)
+{
+    const P2 o = lane == 0 ? a : (lane == 1 ? b : cpt);
+    const double d = dist(ref, o);
+    const double d0 = lane_f64(d, 0), d1 = lane_f64(d, 1), d2 = lane_f64(d, 2);
+    double m = d0 > d1 ? d0 : d1;
+    return d2 > m ? d2 : m;
 }
 
 // ------------------------------------------------------------------------------------------ episode control
@@ -723,7 +756,8 @@ __device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float 
         done = 1;
     } else {
         int mp0, mp1, mp2, mp3, r;
-        bool have_mesh = true, new_vertex = false;
+        bool have_mesh = true, new_vertex = false, have_filter = false;
+        int near_count = 0;
         P2 new_point = mkp(0.0, 0.0);
         int rule;
         if (a0 <= -0.5f) rule = -1;
@@ -745,14 +779,15 @@ __device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float 
             const bool inside = point_inside(c, prm, new_point);
             MESHENV_STAMP(c, 2);
             if (inside) {
-                // find_same_point, B:599-602: first ring vertex within eps
-                bool same = false;
-                for (int i0 = 0; i0 < n && !same; i0 += 64) {
-                    const int i = i0 + lane;
-                    same = __ballot(i < n && dist(ldp(c, i), new_point) < prm.same_eps) != 0ULL;
-                }
-                if (same) rule = -1;  // existing point: the rule -1 quad, B:168-175
-                else new_vertex = true;
+                // second ring pass: find_same_point + the distance filter of the quad [new, i-1, i, i+1]
+                NearFilter f;
+                f.ref = p0;
+                f.mp0 = -1; f.mp1 = wrapi(index - 1, n); f.mp2 = index; f.mp3 = wrapi(index + 1, n);
+                f.max_dist = quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3));
+                bool same;
+                near_count = near_filter_pass(c, f, new_point, prm.same_eps, same);
+                if (same) rule = -1;  // existing point: the rule -1 quad, B:168-175 (its own filter pass follows)
+                else { new_vertex = true; have_filter = true; }
             } else {
                 reward += c.n_elem ? -1.0 / c.n_elem : -1.0;
                 have_mesh = false;
@@ -794,7 +829,19 @@ __device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float 
             MESHENV_STAMP(c, 3);
             bool ok = quad_pass(c, prm, vr, p0, p1, p2, p3, bc0, bc1);
             MESHENV_STAMP(c, 4);
-            if (ok) ok = !intersects_boundary(c, mp0, mp1, mp2, mp3, r);
+            if (ok) {
+                if (!have_filter) {  // rules -1 / +1 (and the same-point case): the filter pass on its own
+                    const double2 *q = c.sc->q;
+                    NearFilter f;
+                    f.ref = mkp(q[r].x, q[r].y);
+                    f.mp0 = mp0; f.mp1 = mp1; f.mp2 = mp2; f.mp3 = mp3;
+                    const double2 qa = q[(r + 1) & 3], qb = q[(r + 2) & 3], qc = q[(r + 3) & 3];
+                    f.max_dist = quad_max_dist(lane, f.ref, mkp(qa.x, qa.y), mkp(qb.x, qb.y), mkp(qc.x, qc.y));
+                    bool unused;
+                    near_count = near_filter_pass(c, f, f.ref, 0.0, unused);
+                }
+                ok = !cross_jobs(c, near_count, mp0, mp1, mp2, mp3, r);
+            }
             MESHENV_STAMP(c, 5);
             if (ok) {
                 const int g0 = mp0 < 0 ? (kNewBit | c.n_new) : c.id[mp0];
