@@ -12,7 +12,7 @@
 //     transcendentals in one pass over a few lanes and broadcasts with v_readlane, so the dependent chain of a
 //     valid extraction is 5 atan2 stages + 1 sincos stage instead of ~25 serial calls.
 //   * wave-uniform control flow (rule type, valid / invalid action) never diverges inside a wave, and a
-//     single-wave workgroup makes __syncthreads() a wave-local LDS fence.
+//     single-wave workgroup makes wave_sync() a wave-local LDS fence.
 // No MFMA: this is branchy fp64 geometry, not a contraction.
 #pragma once
 
@@ -67,6 +67,16 @@ __device__ __forceinline__ P2 ldp(const Ctx &c, int i)
 {
     const double2 v = c.xy[i];
     return mkp(v.x, v.y);
+}
+
+// Fence between LDS phases of ONE wavefront (lanes hand data to each other through LDS).  A wave's LDS
+// instructions execute in issue order, so no hardware wait is needed: this only stops the compiler from moving
+// or caching LDS accesses across the hand-over.  (Workgroup barriers are spelled __syncthreads() and only used by
+// k_step_group between its check and update phases.)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Python list index wrap for i in [-n, 2n)
@@ -127,12 +137,12 @@ __device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env)
         c.key[i] = S.ring_key[c.base + i];
         c.stamp[i] = S.ring_stamp[c.base + i];
     }
-    __syncthreads();
+    wave_sync();
 }
 
 __device__ __forceinline__ void store_env(Ctx &c, const DevState &S)
 {
-    __syncthreads();
+    wave_sync();
     if (c.ring_dirty) {
         for (int i = c.lane; i < c.n; i += 64) {
             S.ring_xy[c.base + i] = c.xy[i];
@@ -217,7 +227,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
 {
     const Params &p = S.prm;
     const int lane = c.lane, n = c.n;
-    __syncthreads();
+    wave_sync();
     const int idx = select_reference(c);
     c.ref = idx;
     MESHENV_STAMP(c, 9);
@@ -322,7 +332,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     const double qy = (0.0 + sr * px) + cr * py;
     const double ux = uniform_f64((ref.x + qx) - ref.x), uy = uniform_f64((ref.y + qy) - ref.y);  // u = p_s - ref
     MESHENV_STAMP(c, 11);
-    __syncthreads();
+    wave_sync();
 
     // ---- stage C: O(n) scan, traversal order ord = 0..n-2 <-> ring index idx-1-ord (C:1239-1267), fused with the
     //      near-vertex scan of compute_boundary_quality (ring index = base + lane)
@@ -417,7 +427,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     const int o0 = (int)(unsigned)k0, o1 = (int)(unsigned)k1, o2 = (int)(unsigned)k2;
     const bool use_hit = rbest < 1.0 && (float)rbest < s1;
     MESHENV_STAMP(c, 13);
-    __syncthreads();
+    wave_sync();
 
     // ---- observation rows
     if (lane < 6) {
@@ -468,7 +478,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
             bq.b_reward = sqrt(q1 * smoothness);  // math.pow(angle_quality * smoothness, 1/2)
         }
     }
-    __syncthreads();
+    wave_sync();
     if (none) {
         c.status |= kStNoReference;
         c.obs = 0.0f;
@@ -643,7 +653,7 @@ __device__ __forceinline__ bool quad_pass(Ctx &c, const Params &prm, const VRing
         }
     }
     const bool any_bad = __ballot(bad) != 0ULL;
-    __syncthreads();
+    wave_sync();
     return !any_bad;
 }
 
@@ -654,7 +664,7 @@ __device__ __forceinline__ bool cross_jobs(Ctx &c, int count, int mp0, int mp1, 
 {
     if (count == 0) return false;
     const int n = c.n, lane = c.lane;
-    __syncthreads();
+    wave_sync();
     const double2 *q = c.sc->q;
     const double2 qa = q[(r + 3) & 3], qb = q[(r + 2) & 3], qc = q[(r + 1) & 3];
     const P2 c0a = mkp(qa.x, qa.y), c0b = mkp(qb.x, qb.y);  // (m[r-1], m[r-2])
@@ -671,7 +681,7 @@ __device__ __forceinline__ bool cross_jobs(Ctx &c, int count, int mp0, int mp1, 
         const bool hit = use && is_cross(ea, eb, ldp(c, i), ldp(c, nb));
         any_hit = __ballot(hit) != 0ULL;
     }
-    __syncthreads();
+    wave_sync();
     return any_hit;
 }
 
@@ -692,7 +702,7 @@ __device__ __forceinline__ void reset_from_domain(Ctx &c, const DevState &S)
 {
     const DomConst dc = S.dom[c.dom];
     const int doff = uniform_i32(dc.off), n0 = uniform_i32(dc.n0);
-    __syncthreads();
+    wave_sync();
     for (int i = c.lane; i < n0; i += 64) {
         c.xy[i] = S.dom_xy[doff + i];
         c.id[i] = i;
@@ -709,7 +719,7 @@ __device__ __forceinline__ void reset_from_domain(Ctx &c, const DevState &S)
     c.status = c.ref < 0 ? kStNoReference : 0;
     c.obs = c.lane < kObsDim ? S.dom_obs[(size_t)c.dom * kObsDim + c.lane] : 0.0f;
     c.ring_dirty = true;
-    __syncthreads();
+    wave_sync();
 }
 
 __device__ __forceinline__ void log_quad(Ctx &c, const DevState &S, int g0, int g1, int g2, int g3)
@@ -732,232 +742,271 @@ struct StepResult {
     bool valid;
 };
 
-// step(action), B:113-263.  a0 = rule type, (a1, a2) = candidate point in the local frame.
-__device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float a0, float a1, float a2)
+// Outcome of the checks of one step(): everything the update needs, so that the checks and the update can run on
+// different wavefronts (k_step_group hands it over through LDS).
+struct Decision {
+    int ok;             // the action extracts a valid element
+    int new_vertex;     // rule 0 with a new vertex (else the quad's two interior ring vertices are removed)
+    int index;          // ring slot of the reference vertex
+    int mp0, mp1, mp2, mp3;  // ring slots of the quad vertices before the update (mp0 = -1: the new vertex)
+    int p0, p1, p2, p3;      // ref_neighbors as ring slots after the update
+    int t0, t1;              // slots of the kept quad vertices after the update
+    int lo, hi;              // removed slots (lo < hi)
+    int done, no_reference;
+    double reward;           // reward accumulated so far (penalties, terminal bonus of B:141-143)
+    P2 new_point;
+};
+
+// Checks of step(action), B:113-191: action decode, rule selection, point-in-polygon / same-point, quad validity,
+// boundary intersection.  a0 = rule type, (a1, a2) = candidate point in the local frame.  On success the quad,
+// its corner angles / edge lengths and the speculative candidate-key and boundary-quality angles are in c.sc.
+__device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a0, float a1, float a2)
 {
     const Params &prm = S.prm;
     const int lane = c.lane;
-    StepResult out;
-    out.valid = false;
-    int done = 0;
-    bool failed = true, no_reference = false;
-    double reward = 0.0;
+    Decision d;
+    d.ok = 0; d.new_vertex = 0; d.done = 0; d.no_reference = 0; d.reward = 0.0;
+    d.index = c.ref;
+    d.mp0 = d.mp1 = d.mp2 = d.mp3 = 0; d.p0 = d.p1 = d.p2 = d.p3 = 0; d.t0 = d.t1 = 0; d.lo = d.hi = 0;
+    d.new_point = mkp(0.0, 0.0);
     const int index = c.ref;
     const int n = c.n;
 
     if (index < 0) {
         // no reference vertex (the reference's find_next_state returned None and its next step() would
         // raise): end the episode as truncated
-        reward = -1.0;
-        done = 1;
-        no_reference = true;
-    } else if (n <= 5) {
-        reward = 10.0;  // B:141-143
-        done = 1;
-    } else {
-        int mp0, mp1, mp2, mp3, r;
-        bool have_mesh = true, new_vertex = false, have_filter = false;
-        int near_count = 0;
-        P2 new_point = mkp(0.0, 0.0);
-        int rule;
-        if (a0 <= -0.5f) rule = -1;
-        else if (a0 >= 0.5f) rule = 1;
-        else {
-            rule = 0;
-            // action_2_point -> detransformation, B:616-625, B:98-106, D:67-83; cos/sin of the frame angle are
-            // per-state values computed with the observation
-            const double px = (double)round4_npf(a1), py = (double)round4_npf(a2);
-            const P2 p0 = ldp(c, index);
-            double ox = c.ct * px + c.st * py;
-            double oy = -c.st * px + c.ct * py;
-            ox *= c.bl;
-            oy *= c.bl;
-            ox += p0.x;
-            oy += p0.y;
-            new_point = mkp(uniform_f64(round4_np(ox)), uniform_f64(round4_np(oy)));
-            MESHENV_STAMP(c, 1);
-            const bool inside = point_inside(c, prm, new_point);
-            MESHENV_STAMP(c, 2);
-            if (inside) {
-                // second ring pass: find_same_point + the distance filter of the quad [new, i-1, i, i+1]
-                NearFilter f;
-                f.ref = p0;
-                f.mp0 = -1; f.mp1 = wrapi(index - 1, n); f.mp2 = index; f.mp3 = wrapi(index + 1, n);
-                f.max_dist = quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3));
-                bool same;
-                near_count = near_filter_pass(c, f, new_point, prm.same_eps, same);
-                if (same) rule = -1;  // existing point: the rule -1 quad, B:168-175 (its own filter pass follows)
-                else { new_vertex = true; have_filter = true; }
-            } else {
-                reward += c.n_elem ? -1.0 / c.n_elem : -1.0;
-                have_mesh = false;
-            }
-        }
-        if (have_mesh) {
-            if (new_vertex) {  // [new, i-1, i, i+1], B:177-182
-                mp0 = -1; mp1 = wrapi(index - 1, n); mp2 = index; mp3 = wrapi(index + 1, n); r = 2;
-            } else if (rule == -1) {  // [i-1, i, i+1, i+2], B:147-153
-                mp0 = wrapi(index - 1, n); mp1 = index; mp2 = wrapi(index + 1, n); mp3 = wrapi(index + 2, n); r = 1;
-            } else {  // [i-2, i-1, i, i+1], B:156-162
-                mp0 = wrapi(index - 2, n); mp1 = wrapi(index - 1, n); mp2 = index; mp3 = wrapi(index + 1, n); r = 2;
-            }
-            // the ring as update_boundary (M:575-648) would leave it, and the slots it touches
-            VRing vr;
-            vr.is_new = new_vertex;
-            vr.new_point = new_point;
-            int p0, p1, p2, p3;  // ref_neighbors as post-update ring slots
-            int t0 = 0, t1 = 0;  // post-update slots of the kept quad vertices
-            int bc0, bc1;
-            if (new_vertex) {
-                vr.n = n; vr.lo = index; vr.hi = -1;
-                p0 = wrapi(index + 1, n); p1 = wrapi(index - 1, n); p2 = wrapi(index + 2, n); p3 = wrapi(index - 2, n);
-                bc0 = wrapi(index + 1, n); bc1 = wrapi(index - 1, n);
-            } else {
-                vr.lo = mp1 < mp2 ? mp1 : mp2; vr.hi = mp1 < mp2 ? mp2 : mp1; vr.n = n - 2;
-                t0 = mp0 - (mp0 > vr.lo ? 1 : 0) - (mp0 > vr.hi ? 1 : 0);
-                t1 = mp3 - (mp3 > vr.lo ? 1 : 0) - (mp3 > vr.hi ? 1 : 0);
-                const int id = t0 > t1 ? t0 : t1, nn = n - 2;
-                p0 = wrapi(id, nn); p1 = wrapi(id - 1, nn); p2 = wrapi(id + 1, nn); p3 = wrapi(id - 2, nn);
-                bc0 = t0; bc1 = t1;
-            }
-            __syncthreads();
-            if (lane < 4) {
-                const int mp = lane == 0 ? mp0 : lane == 1 ? mp1 : lane == 2 ? mp2 : mp3;
-                c.sc->q[lane] = mp < 0 ? make_double2(new_point.x, new_point.y) : c.xy[mp];
-            }
-            __syncthreads();
-            MESHENV_STAMP(c, 3);
-            bool ok = quad_pass(c, prm, vr, p0, p1, p2, p3, bc0, bc1);
-            MESHENV_STAMP(c, 4);
-            if (ok) {
-                if (!have_filter) {  // rules -1 / +1 (and the same-point case): the filter pass on its own
-                    const double2 *q = c.sc->q;
-                    NearFilter f;
-                    f.ref = mkp(q[r].x, q[r].y);
-                    f.mp0 = mp0; f.mp1 = mp1; f.mp2 = mp2; f.mp3 = mp3;
-                    const double2 qa = q[(r + 1) & 3], qb = q[(r + 2) & 3], qc = q[(r + 3) & 3];
-                    f.max_dist = quad_max_dist(lane, f.ref, mkp(qa.x, qa.y), mkp(qb.x, qb.y), mkp(qc.x, qc.y));
-                    bool unused;
-                    near_count = near_filter_pass(c, f, f.ref, 0.0, unused);
-                }
-                ok = !cross_jobs(c, near_count, mp0, mp1, mp2, mp3, r);
-            }
-            MESHENV_STAMP(c, 5);
-            if (ok) {
-                const int g0 = mp0 < 0 ? (kNewBit | c.n_new) : c.id[mp0];
-                const int g1 = c.id[mp1], g2 = c.id[mp2], g3 = c.id[mp3];
-                log_quad(c, S, g0, g1, g2, g3);  // generated_meshes.append, B:192
-
-                // quad terms of the reward (pre-update coordinates; the Mesh holds the Vertex objects)
-                double e_reward;
-                BqArgs bq;
-                {
-                    const double e0 = c.sc->tmp2[0], e1 = c.sc->tmp2[1], e2 = c.sc->tmp2[2], e3 = c.sc->tmp2[3];
-                    const double d02 = c.sc->tmp2[4], d13 = c.sc->tmp2[5];
-                    const double ang0 = c.sc->ang[0], ang1 = c.sc->ang[1], ang2 = c.sc->ang[2], ang3 = c.sc->ang[3];
-                    // Mesh.get_quality('robust'), C:873-884
-                    double mn = e1 < e0 ? e1 : e0;
-                    mn = e2 < mn ? e2 : mn;
-                    mn = e3 < mn ? e3 : mn;
-                    const double q1 = sqrt(2.0) * mn / (d13 > d02 ? d13 : d02);
-                    double amn = ang1 < ang0 ? ang1 : ang0, amx = ang1 > ang0 ? ang1 : ang0;
-                    amn = ang2 < amn ? ang2 : amn; amx = ang2 > amx ? ang2 : amx;
-                    amn = ang3 < amn ? ang3 : amn; amx = ang3 > amx ? ang3 : amx;
-                    e_reward = uniform_f64(sqrt(q1 * (amn / amx)));
-                    // Mesh.compute_area, C:935-950, left-to-right: ((0.5*e0)*e1)*sin(c1) + ((0.5*e2)*e3)*sin(c3);
-                    // corner_1 == corner angle 0, corner_3 == corner angle 2
-                    bq.half01 = uniform_f64(0.5 * e0 * e1);
-                    bq.half23 = uniform_f64(0.5 * e2 * e3);
-                    bq.q_ang0 = ang0;
-                    bq.q_ang2 = ang2;
-                    bq.ang0 = c.sc->tmp[8];
-                    bq.ang1 = c.sc->tmp[9];
-                }
-                // candidate keys of the four ref_neighbors from the speculative job lanes
-                double kk = 0.0;
-                bool okk = false;
-                int pos = 0;
-                if (lane < 4) {
-                    pos = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
-                    okk = key_from_angles(prm, c.sc->tmp[2 * lane], c.sc->tmp[2 * lane + 1], kk);
-                }
-
-                // update_boundary, M:575-648
-                __syncthreads();
-                if (new_vertex) {
-                    if (lane == 0) {
-                        c.xy[index] = make_double2(new_point.x, new_point.y);
-                        c.id[index] = kNewBit | c.n_new;
-                        c.stamp[index] = kNotCand;
-                        const int cap = prm.log_cap;
-                        if (c.n_new < cap) S.log_vxy[(size_t)c.env * cap + c.n_new] = make_double2(new_point.x, new_point.y);
-                    }
-                    if (prm.log_cap > 0 && c.n_new >= prm.log_cap) c.status |= kStLogOverflow;
-                    c.n_new += 1;
-                    bq.mode = 1; bq.a = index; bq.b = 0;
-                } else {
-                    // delete the two interior quad vertices (slots mp1, mp2), compacting the ring in LDS
-                    const int lo = vr.lo, hi = vr.hi;
-                    for (int base = 0; base < n; base += 64) {
-                        const int i = base + lane;
-                        double2 vxy = make_double2(0, 0);
-                        double vk = 0; int vs = 0, vid = 0;
-                        const bool live = i < n && i != lo && i != hi;
-                        if (live) { vxy = c.xy[i]; vk = c.key[i]; vs = c.stamp[i]; vid = c.id[i]; }
-                        __syncthreads();
-                        if (live) {
-                            const int j = i - (i > lo ? 1 : 0) - (i > hi ? 1 : 0);
-                            c.xy[j] = vxy; c.key[j] = vk; c.stamp[j] = vs; c.id[j] = vid;
-                        }
-                        __syncthreads();
-                    }
-                    c.n = n - 2;
-                    bq.mode = 2; bq.a = t0; bq.b = t1;
-                }
-                __syncthreads();
-                // remove_reference_candidates(ref_neighbors [+ removed]) then add_reference_candidates in order
-                {
-                    const unsigned long long mk = __ballot(okk);
-                    if (lane < 4) {
-                        if (okk) {
-                            c.key[pos] = kk;
-                            c.stamp[pos] = c.counter + __popcll(mk & ((2ULL << lane) - 1ULL));
-                        } else {
-                            c.stamp[pos] = kNotCand;
-                        }
-                    }
-                    c.counter += __popcll(mk);
-                }
-                MESHENV_STAMP(c, 6);
-                failed = false;
-                out.valid = true;
-                c.ring_dirty = true;
-                const bool finished = c.n <= 5;  // B:232-238
-                if (finished && c.n == 4) log_quad(c, S, c.id[0], c.id[1], c.id[2], c.id[3]);
-                // current_area -= mesh_area (B:200) happens inside: the area needs sin(corner angles), a stage-B job
-                find_next_state(c, S, bq);
-                MESHENV_STAMP(c, 14);
-                const double mesh_area = bq.mesh_area;
-                // get_quality(mesh, 2), M:1733-1740
-                const double quality = e_reward + 1 * (bq.b_reward - 1);
-                // get_speed_penalty, B:434-450
-                const DomConst &dc = S.dom[c.dom];
-                const double min_area = dc.min_area, crit_area = dc.crit_area;
-                double speed = 0.0;
-                if (min_area <= mesh_area && mesh_area < crit_area) speed = (mesh_area - crit_area) / (crit_area - min_area);
-                else if (mesh_area < min_area) speed = -1.0;
-                reward += quality + speed;
-                if (finished) {
-                    reward += 10.0;
-                    done = 1;
-                }
-            } else {
-                reward += c.n_elem ? -1.0 / c.n_elem : -1.0;  // B:248
-            }
-        }
+        d.reward = -1.0;
+        d.done = 1;
+        d.no_reference = 1;
+        return d;
     }
-    int complete = no_reference ? 0 : 1;
-    if (!failed) {
+    if (n <= 5) {
+        d.reward = 10.0;  // B:141-143
+        d.done = 1;
+        return d;
+    }
+    int mp0, mp1, mp2, mp3, r;
+    bool new_vertex = false, have_filter = false;
+    int near_count = 0;
+    P2 new_point = mkp(0.0, 0.0);
+    int rule;
+    if (a0 <= -0.5f) rule = -1;
+    else if (a0 >= 0.5f) rule = 1;
+    else {
+        rule = 0;
+        // action_2_point -> detransformation, B:616-625, B:98-106, D:67-83; cos/sin of the frame angle are
+        // per-state values computed with the observation
+        const double px = (double)round4_npf(a1), py = (double)round4_npf(a2);
+        const P2 p0 = ldp(c, index);
+        double ox = c.ct * px + c.st * py;
+        double oy = -c.st * px + c.ct * py;
+        ox *= c.bl;
+        oy *= c.bl;
+        ox += p0.x;
+        oy += p0.y;
+        new_point = mkp(uniform_f64(round4_np(ox)), uniform_f64(round4_np(oy)));
+        MESHENV_STAMP(c, 1);
+        const bool inside = point_inside(c, prm, new_point);
+        MESHENV_STAMP(c, 2);
+        if (!inside) {
+            d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;
+            return d;
+        }
+        // second ring pass: find_same_point + the distance filter of the quad [new, i-1, i, i+1]
+        NearFilter f;
+        f.ref = p0;
+        f.mp0 = -1; f.mp1 = wrapi(index - 1, n); f.mp2 = index; f.mp3 = wrapi(index + 1, n);
+        f.max_dist = quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3));
+        bool same;
+        near_count = near_filter_pass(c, f, new_point, prm.same_eps, same);
+        if (same) rule = -1;  // existing point: the rule -1 quad, B:168-175 (its own filter pass follows)
+        else { new_vertex = true; have_filter = true; }
+    }
+    if (new_vertex) {  // [new, i-1, i, i+1], B:177-182
+        mp0 = -1; mp1 = wrapi(index - 1, n); mp2 = index; mp3 = wrapi(index + 1, n); r = 2;
+    } else if (rule == -1) {  // [i-1, i, i+1, i+2], B:147-153
+        mp0 = wrapi(index - 1, n); mp1 = index; mp2 = wrapi(index + 1, n); mp3 = wrapi(index + 2, n); r = 1;
+    } else {  // [i-2, i-1, i, i+1], B:156-162
+        mp0 = wrapi(index - 2, n); mp1 = wrapi(index - 1, n); mp2 = index; mp3 = wrapi(index + 1, n); r = 2;
+    }
+    // the ring as update_boundary (M:575-648) would leave it, and the slots it touches
+    VRing vr;
+    vr.is_new = new_vertex;
+    vr.new_point = new_point;
+    int p0, p1, p2, p3;  // ref_neighbors as post-update ring slots
+    int t0 = 0, t1 = 0;  // post-update slots of the kept quad vertices
+    int bc0, bc1;
+    if (new_vertex) {
+        vr.n = n; vr.lo = index; vr.hi = -1;
+        p0 = wrapi(index + 1, n); p1 = wrapi(index - 1, n); p2 = wrapi(index + 2, n); p3 = wrapi(index - 2, n);
+        bc0 = wrapi(index + 1, n); bc1 = wrapi(index - 1, n);
+    } else {
+        vr.lo = mp1 < mp2 ? mp1 : mp2; vr.hi = mp1 < mp2 ? mp2 : mp1; vr.n = n - 2;
+        t0 = mp0 - (mp0 > vr.lo ? 1 : 0) - (mp0 > vr.hi ? 1 : 0);
+        t1 = mp3 - (mp3 > vr.lo ? 1 : 0) - (mp3 > vr.hi ? 1 : 0);
+        const int id = t0 > t1 ? t0 : t1, nn = n - 2;
+        p0 = wrapi(id, nn); p1 = wrapi(id - 1, nn); p2 = wrapi(id + 1, nn); p3 = wrapi(id - 2, nn);
+        bc0 = t0; bc1 = t1;
+    }
+    wave_sync();
+    if (lane < 4) {
+        const int mp = lane == 0 ? mp0 : lane == 1 ? mp1 : lane == 2 ? mp2 : mp3;
+        c.sc->q[lane] = mp < 0 ? make_double2(new_point.x, new_point.y) : c.xy[mp];
+    }
+    wave_sync();
+    MESHENV_STAMP(c, 3);
+    bool ok = quad_pass(c, prm, vr, p0, p1, p2, p3, bc0, bc1);
+    MESHENV_STAMP(c, 4);
+    if (ok) {
+        if (!have_filter) {  // rules -1 / +1 (and the same-point case): the filter pass on its own
+            const double2 *q = c.sc->q;
+            NearFilter f;
+            f.ref = mkp(q[r].x, q[r].y);
+            f.mp0 = mp0; f.mp1 = mp1; f.mp2 = mp2; f.mp3 = mp3;
+            const double2 qa = q[(r + 1) & 3], qb = q[(r + 2) & 3], qc = q[(r + 3) & 3];
+            f.max_dist = quad_max_dist(lane, f.ref, mkp(qa.x, qa.y), mkp(qb.x, qb.y), mkp(qc.x, qc.y));
+            bool unused;
+            near_count = near_filter_pass(c, f, f.ref, 0.0, unused);
+        }
+        ok = !cross_jobs(c, near_count, mp0, mp1, mp2, mp3, r);
+    }
+    MESHENV_STAMP(c, 5);
+    if (!ok) {
+        d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;  // B:248
+        return d;
+    }
+    d.ok = 1;
+    d.new_vertex = new_vertex ? 1 : 0;
+    d.mp0 = mp0; d.mp1 = mp1; d.mp2 = mp2; d.mp3 = mp3;
+    d.p0 = p0; d.p1 = p1; d.p2 = p2; d.p3 = p3;
+    d.t0 = t0; d.t1 = t1;
+    d.lo = vr.lo; d.hi = vr.hi;
+    d.new_point = new_point;
+    return d;
+}
+
+// The extraction itself, B:192-238 + find_next_state: element log, ring update, candidate list patch, reward,
+// next observation.  Runs on whichever wavefront holds the env's LDS region (c) and the decision.
+__device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d)
+{
+    const Params &prm = S.prm;
+    const int lane = c.lane;
+    const int n = c.n, index = d.index;
+    const bool new_vertex = d.new_vertex != 0;
+    const int g0 = d.mp0 < 0 ? (kNewBit | c.n_new) : c.id[d.mp0];
+    const int g1 = c.id[d.mp1], g2 = c.id[d.mp2], g3 = c.id[d.mp3];
+    log_quad(c, S, g0, g1, g2, g3);  // generated_meshes.append, B:192
+
+    // quad terms of the reward (pre-update coordinates; the Mesh holds the Vertex objects)
+    double e_reward;
+    BqArgs bq;
+    {
+        const double e0 = c.sc->tmp2[0], e1 = c.sc->tmp2[1], e2 = c.sc->tmp2[2], e3 = c.sc->tmp2[3];
+        const double d02 = c.sc->tmp2[4], d13 = c.sc->tmp2[5];
+        const double ang0 = c.sc->ang[0], ang1 = c.sc->ang[1], ang2 = c.sc->ang[2], ang3 = c.sc->ang[3];
+        // Mesh.get_quality('robust'), C:873-884
+        double mn = e1 < e0 ? e1 : e0;
+        mn = e2 < mn ? e2 : mn;
+        mn = e3 < mn ? e3 : mn;
+        const double q1 = sqrt(2.0) * mn / (d13 > d02 ? d13 : d02);
+        double amn = ang1 < ang0 ? ang1 : ang0, amx = ang1 > ang0 ? ang1 : ang0;
+        amn = ang2 < amn ? ang2 : amn; amx = ang2 > amx ? ang2 : amx;
+        amn = ang3 < amn ? ang3 : amn; amx = ang3 > amx ? ang3 : amx;
+        e_reward = uniform_f64(sqrt(q1 * (amn / amx)));
+        // Mesh.compute_area, C:935-950, left-to-right: ((0.5*e0)*e1)*sin(c1) + ((0.5*e2)*e3)*sin(c3);
+        // corner_1 == corner angle 0, corner_3 == corner angle 2
+        bq.half01 = uniform_f64(0.5 * e0 * e1);
+        bq.half23 = uniform_f64(0.5 * e2 * e3);
+        bq.q_ang0 = ang0;
+        bq.q_ang2 = ang2;
+        bq.ang0 = c.sc->tmp[8];
+        bq.ang1 = c.sc->tmp[9];
+    }
+    // candidate keys of the four ref_neighbors from the speculative job lanes
+    double kk = 0.0;
+    bool okk = false;
+    int pos = 0;
+    if (lane < 4) {
+        pos = lane == 0 ? d.p0 : lane == 1 ? d.p1 : lane == 2 ? d.p2 : d.p3;
+        okk = key_from_angles(prm, c.sc->tmp[2 * lane], c.sc->tmp[2 * lane + 1], kk);
+    }
+
+    // update_boundary, M:575-648
+    wave_sync();
+    if (new_vertex) {
+        if (lane == 0) {
+            c.xy[index] = make_double2(d.new_point.x, d.new_point.y);
+            c.id[index] = kNewBit | c.n_new;
+            c.stamp[index] = kNotCand;
+            const int cap = prm.log_cap;
+            if (c.n_new < cap) S.log_vxy[(size_t)c.env * cap + c.n_new] = make_double2(d.new_point.x, d.new_point.y);
+        }
+        if (prm.log_cap > 0 && c.n_new >= prm.log_cap) c.status |= kStLogOverflow;
+        c.n_new += 1;
+        bq.mode = 1; bq.a = index; bq.b = 0;
+    } else {
+        // delete the two interior quad vertices (slots mp1, mp2), compacting the ring in LDS
+        const int lo = d.lo, hi = d.hi;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            double2 vxy = make_double2(0, 0);
+            double vk = 0; int vs = 0, vid = 0;
+            const bool live = i < n && i != lo && i != hi;
+            if (live) { vxy = c.xy[i]; vk = c.key[i]; vs = c.stamp[i]; vid = c.id[i]; }
+            wave_sync();
+            if (live) {
+                const int j = i - (i > lo ? 1 : 0) - (i > hi ? 1 : 0);
+                c.xy[j] = vxy; c.key[j] = vk; c.stamp[j] = vs; c.id[j] = vid;
+            }
+            wave_sync();
+        }
+        c.n = n - 2;
+        bq.mode = 2; bq.a = d.t0; bq.b = d.t1;
+    }
+    wave_sync();
+    // remove_reference_candidates(ref_neighbors [+ removed]) then add_reference_candidates in order
+    {
+        const unsigned long long mk = __ballot(okk);
+        if (lane < 4) {
+            if (okk) {
+                c.key[pos] = kk;
+                c.stamp[pos] = c.counter + __popcll(mk & ((2ULL << lane) - 1ULL));
+            } else {
+                c.stamp[pos] = kNotCand;
+            }
+        }
+        c.counter += __popcll(mk);
+    }
+    MESHENV_STAMP(c, 6);
+    c.ring_dirty = true;
+    const bool finished = c.n <= 5;  // B:232-238
+    if (finished && c.n == 4) log_quad(c, S, c.id[0], c.id[1], c.id[2], c.id[3]);
+    // current_area -= mesh_area (B:200) happens inside: the area needs sin(corner angles), a stage-B job
+    find_next_state(c, S, bq);
+    MESHENV_STAMP(c, 14);
+    const double mesh_area = bq.mesh_area;
+    // get_quality(mesh, 2), M:1733-1740
+    const double quality = e_reward + 1 * (bq.b_reward - 1);
+    // get_speed_penalty, B:434-450
+    const DomConst &dc = S.dom[c.dom];
+    const double min_area = dc.min_area, crit_area = dc.crit_area;
+    double speed = 0.0;
+    if (min_area <= mesh_area && mesh_area < crit_area) speed = (mesh_area - crit_area) / (crit_area - min_area);
+    else if (mesh_area < min_area) speed = -1.0;
+    d.reward += quality + speed;
+    if (finished) {
+        d.reward += 10.0;
+        d.done = 1;
+    }
+}
+
+// failed_num bookkeeping and the 100-failure truncation, B:253-263
+__device__ __forceinline__ StepResult env_finish(Ctx &c, const Params &prm, const Decision &d)
+{
+    StepResult out;
+    out.valid = d.ok != 0;
+    int done = d.done, complete = d.no_reference ? 0 : 1;
+    if (d.ok) {
         c.failed = 0;
     } else {
         // the observation of an unchanged state is the cached one (find_next_state is a pure function of
@@ -968,10 +1017,18 @@ __device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float 
             complete = 0;
         }
     }
-    out.reward = reward;
+    out.reward = d.reward;
     out.done = done;
     out.complete = complete;
     return out;
+}
+
+// step(action), B:113-263, on one wavefront
+__device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float a0, float a1, float a2)
+{
+    Decision d = env_check(c, S, a0, a1, a2);
+    if (d.ok) env_apply(c, S, d);
+    return env_finish(c, S.prm, d);
 }
 
 // ------------------------------------------------------------------------------------------ kernels
@@ -998,7 +1055,7 @@ __global__ void __launch_bounds__(64) k_init_domains(DevState S, int cap)
         c.xy[i] = S.dom_xy[doff + i];
         c.id[i] = i;
     }
-    __syncthreads();
+    wave_sync();
     // find_reference_candidates, M:233-261: stable sort by key -> ties in ring order (stamp = -index)
     for (int i = c.lane; i < c.n; i += 64) {
         double cc, dd, k = 0.0;
@@ -1082,7 +1139,7 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
 #ifdef MESHENV_STAMPS
     const unsigned long long stamp_t1 = __builtin_amdgcn_s_memrealtime();
     if (c.lane < 16) c.sc->stamps[c.lane] = 0;
-    __syncthreads();
+    wave_sync();
 #endif
     unsigned long long st_valid = 0, st_sum = 0, st_sumv = 0;
     const int T = kMulti ? n_steps : 1;
@@ -1117,7 +1174,7 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
         S.cnt[env] = k;
     }
     if (c.lane == 0) c.sc->stamps[15] = __builtin_amdgcn_s_memtime() - stamp_c0;
-    __syncthreads();
+    wave_sync();
     if (c.lane < 16) S.dbg[(size_t)env * 16 + c.lane] = c.sc->stamps[c.lane];
 #else
     if (c.lane == 0) {

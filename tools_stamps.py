@@ -55,3 +55,13 @@ for e in order:
         if st[e,k]>0: ds.append(f"{k}:{(st[e,k]-prev)*tick:.1f}"); prev=st[e,k]
     print(e, f"{dur[e]:.1f}", f"{(t0[e]-base)*tick:.1f}", int(valid[e]), int(rule[e]), " ".join(ds), f"tail:{(t2[e]-prev)*tick:.1f}")
 print("valid dur percentiles 50/90/99/100:", np.percentile(dur[valid],[50,90,99,100]))
+hw=st[:,0]
+# gfx9 HW_ID: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13](+) ...; use all bits above wave_id as the SIMD key
+simd_key=((hw>>4)&0xfff) | ((hw>>32)<<12)   # simd, pipe, cu, sh, se + xcc
+import collections
+cntv=collections.Counter(simd_key[valid].tolist())
+share=np.array([cntv[k] for k in simd_key])
+for m in sorted(set(share[valid].tolist())):
+    sel=valid&(share==m)
+    print(f"valid waves with {m} valid wave(s) on their SIMD: n={sel.sum():4d} dur mean={dur[sel].mean():6.2f} max={dur[sel].max():6.2f}")
+print("distinct SIMD keys:", len(set(simd_key.tolist())))
