@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,6 +28,8 @@ struct MeshEnv {
     DevState S{};
     int n_envs = 0, n_domains = 0, cap = 0, max_ring = 0;
     size_t lds = 0;
+    int group = 1;        // environments (wavefronts) per workgroup of the single-step kernel
+    size_t group_lds = 0;
     std::vector<int32_t> dom_off_host, env_dom_host;
     std::vector<void *> allocs;
     std::string err;
@@ -187,6 +190,21 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
         CREATE_HIP(hipFuncSetAttribute((const void *)k_init_domains, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
 
+    // single-step kernel: as many envs per workgroup as one CU's LDS holds (16 = the CU's full wave complement)
+    {
+        int G = 1;
+        const char *force = getenv("MESHENV_GROUP");
+        const int want = force ? atoi(force) : 16;
+        for (int g : {16, 8, 4})
+            if (g <= want && group_lds_bytes(cap, g) <= 150 * 1024) { G = g; break; }
+        h->group = G;
+        h->group_lds = group_lds_bytes(cap, G);
+        if (G > 1 && h->group_lds > 64 * 1024) {
+            const void *fn = G == 16 ? (const void *)k_step_group<16> : G == 8 ? (const void *)k_step_group<8> : (const void *)k_step_group<4>;
+            CREATE_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->group_lds));
+        }
+    }
+
     DevState &S = h->S;
     S.n_domains = n_domains;
     S.n_envs = n_envs;
@@ -291,7 +309,19 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
     const size_t slot = (size_t)(h->ev_count % MESHENV_TIMING_POOL);
     const bool timed = h->timing > 0 && (h->launch_count++ % h->timing) == 0;
     if (timed) HIP_TRY(h, hipEventRecord(h->ev[2 * slot], h->stream));
-    if (n_steps == 1)
+    if (n_steps == 1 && h->group > 1) {
+        const int G = h->group;
+        const dim3 grid((h->n_envs + G - 1) / G), block(64 * G);
+        if (G == 16)
+            hipLaunchKernelGGL(k_step_group<16>, grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
+                               reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
+        else if (G == 8)
+            hipLaunchKernelGGL(k_step_group<8>, grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
+                               reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
+        else
+            hipLaunchKernelGGL(k_step_group<4>, grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
+                               reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
+    } else if (n_steps == 1)
         hipLaunchKernelGGL(k_step<false>, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, 1, actions_dev, obs_dev,
                            reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
     else

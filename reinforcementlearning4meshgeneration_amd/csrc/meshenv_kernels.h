@@ -84,7 +84,7 @@ __device__ __forceinline__ int wrapi(int i, int n) { return i < 0 ? i + n : (i >
 
 __host__ __device__ __forceinline__ size_t lds_bytes_for(int cap)
 {
-    return (size_t)cap * (sizeof(double2) + 2 * sizeof(double) + 3 * sizeof(int32_t)) + sizeof(Scratch) + 64;
+    return ((size_t)cap * (sizeof(double2) + 2 * sizeof(double) + 3 * sizeof(int32_t)) + sizeof(Scratch) + 64 + 15) / 16 * 16;
 }
 
 __device__ __forceinline__ void carve_lds(Ctx &c, void *smem, int cap)
@@ -1183,6 +1183,157 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
         S.cnt[env] = k;
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------ CU-group step kernel
+
+// What a wavefront leaves in LDS for the wavefront that will run the update of its environment.
+struct alignas(32) Handoff {
+    int valid;  // the checks passed: an update is pending
+    int simd;   // hardware SIMD the checking wave runs on
+    int env, n, ref, n_elem, failed, n_new, counter, status, dom, pad;
+    double bl, area, ct, st;
+    EnvCounters cnt0;
+    Decision d;
+};
+
+__host__ __device__ __forceinline__ size_t group_lds_bytes(int cap, int G)
+{
+    return (size_t)G * (lds_bytes_for(cap) + sizeof(Handoff));
+}
+
+// reward / flags / observation of one finished step, auto-reset, state write-back, work counters
+__device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, const Decision &d, const EnvCounters &cnt0,
+                                                 int n_before, float *__restrict__ obs_out, double *__restrict__ reward,
+                                                 uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
+                                                 float *__restrict__ term_obs, int auto_reset)
+{
+    const StepResult r = env_finish(c, S.prm, d);
+    const int env = c.env;
+    if (c.lane == 0) {
+        reward[env] = r.reward;
+        done[env] = (uint8_t)r.done;
+        complete[env] = (uint8_t)r.complete;
+    }
+    if (r.done) {
+        if (term_obs && c.lane < kObsDim) term_obs[(size_t)env * kObsDim + c.lane] = c.obs;
+        if (auto_reset) reset_from_domain(c, S);
+    }
+    if (c.lane < kObsDim) obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
+    store_env(c, S);
+    if (c.lane == 0) {
+        EnvCounters k = cnt0;
+        k.steps += 1ULL;
+        k.sum_n += (unsigned long long)n_before;
+        if (r.valid) { k.valid += 1ULL; k.sum_n_valid += (unsigned long long)n_before; }
+        S.cnt[env] = k;
+    }
+}
+
+// One step() of every env with G environments (wavefronts) per workgroup, one workgroup per CU-sized slice.
+//
+// Why: ~12 % of the steps extract an element and take ~4x longer than a rejected action; with one wave per
+// workgroup those long waves land on SIMDs at random, and the launch ends with the SIMD that happens to hold three or
+// four of them (measured: 12.2 us alone on a SIMD, 13.3 / 14.8 / 16.8 us with 2 / 3 / 4 -- profiles/, tools_stamps.py).
+// Here every wave runs the CHECKS of its own env (phase 1), the workgroup meets at one barrier, and the pending
+// UPDATES are dealt round-robin over the four SIMDs of the CU (phase 2): wave (simd s, r-th on that SIMD) takes the
+// (4r+s)-th pending env of the group.  The env's ring never moves -- it is already in the workgroup's LDS -- only
+// ~40 scalars are handed over (Handoff).  Environments stay independent: no data is shared between envs.
+template <int G>
+__global__ void __launch_bounds__(64 * G)
+k_step_group(DevState S, int cap, const float *__restrict__ actions, float *__restrict__ obs_out,
+             double *__restrict__ reward, uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
+             float *__restrict__ term_obs, int auto_reset)
+{
+    extern __shared__ double2 smem[];
+    const int wave = threadIdx.x >> 6;
+    const size_t env_bytes = lds_bytes_for(cap);
+    Handoff *ho = (Handoff *)((char *)smem + (size_t)G * env_bytes);
+    const int env = blockIdx.x * G + wave;
+    const bool active = env < S.n_envs;
+    int pending = 0;
+    if (active) {
+        Ctx c;
+        carve_lds(c, (char *)smem + (size_t)wave * env_bytes, cap);
+        const float *a = actions + (size_t)env * 3;
+        const float a0 = a[0], a1 = a[1], a2 = a[2];
+        const EnvCounters cnt0 = S.cnt[env];
+        load_env(c, S, env);
+        const int n_before = c.n;
+        Decision d = env_check(c, S, a0, a1, a2);
+        if (!d.ok) {
+            finish_and_store(c, S, d, cnt0, n_before, obs_out, reward, done, complete, term_obs, auto_reset);
+        } else {
+            pending = 1;
+            if (c.lane == 0) {
+                Handoff &h = ho[wave];
+                h.env = env; h.n = c.n; h.ref = c.ref; h.n_elem = c.n_elem; h.failed = c.failed; h.n_new = c.n_new;
+                h.counter = c.counter; h.status = c.status; h.dom = c.dom;
+                h.bl = c.bl; h.area = c.area; h.ct = c.ct; h.st = c.st;
+                h.cnt0 = cnt0;
+                h.d = d;
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        ho[wave].valid = pending;
+        ho[wave].simd = (int)__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11));  // HW_REG_HW_ID.simd_id
+    }
+    __syncthreads();
+
+    // ---- deal the pending updates over the SIMDs
+    unsigned vmask = 0, smask[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < G; w++) {
+        const int v = ho[w].valid, sd = ho[w].simd & 3;
+        vmask |= (unsigned)(v != 0) << w;
+        smask[0] |= (unsigned)(sd == 0) << w;
+        smask[1] |= (unsigned)(sd == 1) << w;
+        smask[2] |= (unsigned)(sd == 2) << w;
+        smask[3] |= (unsigned)(sd == 3) << w;
+    }
+    vmask = (unsigned)uniform_i32((int)vmask);
+    const int m = __popc(vmask);
+    if (m == 0) return;
+    const int my_simd = uniform_i32(ho[wave].simd & 3);
+    const unsigned mine = (unsigned)uniform_i32((int)(my_simd == 0 ? smask[0] : my_simd == 1 ? smask[1] : my_simd == 2 ? smask[2] : smask[3]));
+    const bool balanced = __popc((unsigned)uniform_i32((int)smask[0])) * 4 == G && __popc((unsigned)uniform_i32((int)smask[1])) * 4 == G &&
+                          __popc((unsigned)uniform_i32((int)smask[2])) * 4 == G && __popc((unsigned)uniform_i32((int)smask[3])) * 4 == G;
+    int src = -1;
+    if (balanced && G >= 4) {
+        const int j = __popc(mine & ((1u << wave) - 1u)) * 4 + my_simd;  // my turn in the deal
+        if (j < m) {
+            unsigned rest = vmask;
+            for (int t = 0; t < j; t++) rest &= rest - 1u;  // drop the j lowest pending waves
+            src = __ffs((int)rest) - 1;
+        }
+    } else if (vmask & (1u << wave)) {
+        src = wave;  // waves not spread evenly over the SIMDs: everybody keeps its own env
+    }
+    if (src < 0) return;
+
+    // ---- phase 2: the update of env ho[src], in place in its LDS region
+    Ctx c;
+    carve_lds(c, (char *)smem + (size_t)src * env_bytes, cap);
+    const Handoff &h = ho[src];
+    c.lane = threadIdx.x & 63;
+    c.env = uniform_i32(h.env);
+    c.base = (size_t)c.env * S.cap;
+    c.n = uniform_i32(h.n); c.ref = uniform_i32(h.ref); c.n_elem = uniform_i32(h.n_elem); c.failed = uniform_i32(h.failed);
+    c.n_new = uniform_i32(h.n_new); c.counter = uniform_i32(h.counter); c.status = uniform_i32(h.status); c.dom = uniform_i32(h.dom);
+    c.bl = uniform_f64(h.bl); c.area = uniform_f64(h.area); c.ct = uniform_f64(h.ct); c.st = uniform_f64(h.st);
+    c.ring_dirty = false;
+    c.obs = 0.0f;
+    Decision d = h.d;
+    d.index = uniform_i32(d.index); d.new_vertex = uniform_i32(d.new_vertex);
+    d.mp0 = uniform_i32(d.mp0); d.mp1 = uniform_i32(d.mp1); d.mp2 = uniform_i32(d.mp2); d.mp3 = uniform_i32(d.mp3);
+    d.p0 = uniform_i32(d.p0); d.p1 = uniform_i32(d.p1); d.p2 = uniform_i32(d.p2); d.p3 = uniform_i32(d.p3);
+    d.t0 = uniform_i32(d.t0); d.t1 = uniform_i32(d.t1); d.lo = uniform_i32(d.lo); d.hi = uniform_i32(d.hi);
+    d.ok = 1;
+    const EnvCounters cnt0 = h.cnt0;
+    const int n_before = c.n;
+    env_apply(c, S, d);
+    finish_and_store(c, S, d, cnt0, n_before, obs_out, reward, done, complete, term_obs, auto_reset);
 }
 
 }  // namespace meshenv
