@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-every", type=int, default=8, help="N > 1: steps per all-gather bucket")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-process flow on a one-GPU box together with MESHENV_BENCH_DEVICE=0)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--time-every", type=int, default=8, help="HIP-event-time every k-th launch of the timed region")
     args = ap.parse_args()
@@ -106,10 +109,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    pg_up = False
+    if "MESHENV_BENCH_DEVICE" in os.environ:  # rehearsal: several ranks on one GPU (gloo backend only)
+        local_rank = int(os.environ["MESHENV_BENCH_DEVICE"])
+    if world > 1 or os.environ.get("MESHENV_BENCH_FORCE_GATHER") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        pg_up = True
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
@@ -124,21 +135,45 @@ def main():
     actions = (lo + (hi - lo) * torch.rand((K + W, n, 3), device=dev, generator=gen)).to(torch.float32).contiguous()
 
     # packed exchange message for N > 1: [obs(18) | reward | done | complete] per env, float32
-    if world > 1:
-        msg = torch.empty((n, 21), dtype=torch.float32, device=dev)
-        gathered = torch.empty((world * n, 21), dtype=torch.float32, device=dev)
+    from reinforcementlearning4meshgeneration_amd import sharding
+    do_gather = world > 1 or os.environ.get("MESHENV_BENCH_FORCE_GATHER") == "1"
+    GS = max(1, args.gather_every)
+    if do_gather:
+        # The step kernel writes the [n, 21] message of step t into slot t % GS of a [GS, n, 21] bucket; one
+        # all_gather_into_tensor per bucket (RCCL, its own stream) overlaps the next bucket's steps -- actors run their
+        # own policy copy, the gathered transitions feed the learner's replay buffer.  Two buckets, so a
+        # bucket is only rewritten after its collective has completed.  One collective per GS steps keeps the
+        # ~25 us host cost of a collective call off the per-step path.
+        on_dev = args.backend == "nccl"
+        buckets = [torch.zeros((GS, n, sharding.MSG_DIM), dtype=torch.float32, device=dev) for _ in range(2)]
+        gdev = dev if on_dev else torch.device("cpu")
+        gath = [torch.empty((world * GS, n, sharding.MSG_DIM), dtype=torch.float32, device=gdev) for _ in range(2)]  # rank-major
+        works = [None, None]
 
     def one_step(t):
-        obs, rew, done, comp = env.step(actions[t])
-        if world > 1:
-            msg[:, :18] = obs
-            msg[:, 18] = rew
-            msg[:, 19] = done
-            msg[:, 20] = comp
-            dist.all_gather_into_tensor(gathered, msg)
+        if do_gather:
+            slot, b = t % GS, (t // GS) & 1
+            if slot == 0 and works[b] is not None:
+                works[b].wait()          # stream-level wait for the collective that last used this bucket
+                works[b] = None
+            env.set_packed_output(buckets[b][slot])
+        env.step(actions[t])
+        if do_gather and slot == GS - 1:
+            if on_dev:
+                works[b] = dist.all_gather_into_tensor(gath[b], buckets[b], async_op=True)
+            else:
+                dist.all_gather_into_tensor(gath[b], buckets[b].cpu())
+
+    def drain():
+        if do_gather:
+            for b in (0, 1):
+                if works[b] is not None:
+                    works[b].wait()
+                    works[b] = None
 
     for t in range(W):
         one_step(t)
+    drain()
     torch.cuda.synchronize()
     c0 = env.counters()
     if not args.no_kernel_timing:
@@ -149,6 +184,7 @@ def main():
     t0 = time.perf_counter()
     for t in range(W, W + K):
         one_step(t)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -161,7 +197,7 @@ def main():
         env.set_timing(0)
     c1 = env.counters()
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -176,7 +212,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n} vectorised boundary() envs per GPU (general/polygon.py:79-83, 30-vertex ring), "
                                "uniform-random float32 actions resident in HBM, auto-reset, one meshenv_step launch "
-                               "per vector step" + (", + RCCL all-gather of [n,21] f32 obs/reward/done message" if world > 1 else ""),
+                               "per vector step" + (f", + one async RCCL all-gather per {GS} steps of the [{GS},n,21] f32 obs/reward/done bucket written by the kernel" if world > 1 else ""),
                    "n_envs_per_gpu": n, "n_envs_total": n * world, "parallelism": f"env-shard x{world}",
                    "valid_action_rate": d["valid"] / max(1, d["steps"]), "mean_ring_len": d["sum_ring"] / max(1, d["steps"])},
     }
@@ -194,7 +230,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(n, seed=99)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg_up:
         dist.destroy_process_group()
 
 

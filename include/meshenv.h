@@ -142,6 +142,15 @@ int meshenv_step(MeshEnv *h, const float *actions_dev, float *obs_dev, double *r
 int meshenv_rollout(MeshEnv *h, int n_steps, const float *actions_dev, float *obs_dev, double *reward_dev,
                     uint8_t *done_dev, uint8_t *complete_dev, int auto_reset);
 
+/*
+ * Multi-GPU exchange message.  With msg_dev != NULL every following meshenv_step / meshenv_rollout also writes
+ * msg_dev[n_envs*21] float32 = (obs[18] | reward | done | complete) per env -- the buffer a rank hands to
+ * all_gather -- straight from the step kernel (no separate pack kernels).  NULL switches it off.  The pointer
+ * may be changed between steps (double buffering against an in-flight collective).
+ */
+#define MESHENV_MSG_DIM 21
+int meshenv_set_packed_output(MeshEnv *h, float *msg_dev);
+
 /* Per-env status bits (MESHENV_ST_*) after the last step/reset; status_dev[n_envs]. */
 int meshenv_get_status(MeshEnv *h, uint8_t *status_dev);
 

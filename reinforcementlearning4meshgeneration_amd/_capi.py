@@ -35,7 +35,7 @@ EXPORTS = [
     "meshenv_default_params", "meshenv_abi_version", "meshenv_device_count", "meshenv_create", "meshenv_destroy",
     "meshenv_last_error", "meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_reset",
     "meshenv_step", "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",
-    "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times", "meshenv_selftest",
+    "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times", "meshenv_selftest", "meshenv_set_packed_output",
 ]
 
 
@@ -76,6 +76,8 @@ def load():
     L.meshenv_kernel_times.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int32)]
     L.meshenv_selftest.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.meshenv_selftest.restype = C.c_int
+    L.meshenv_set_packed_output.argtypes = [vp, vp]
+    L.meshenv_set_packed_output.restype = C.c_int
     for name in ("meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_reset", "meshenv_step",
                  "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",
                  "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times"):

@@ -190,11 +190,20 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
         CREATE_HIP(hipFuncSetAttribute((const void *)k_init_domains, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
 
-    // single-step kernel: as many envs per workgroup as one CU's LDS holds (16 = the CU's full wave complement)
+    // Single-step kernel variant.  The CU-group kernel (G envs per workgroup, SIMD-balanced updates) pays off in the
+    // latency-bound regime only: one workgroup per CU (n_envs <= 256 * G) with G >= 8; measured on MI355X,
+    // boundary(): 4096 envs 20.2 -> 19.4 us/step (G = 16), 2048 envs 16.5 -> 16.0 (G = 8), but 8192 envs
+    // 25.0 -> 34.6 and 65536 envs 103 -> 231 us/step, where throughput, not the slowest wave, sets the time.
     {
         int G = 1;
         const char *force = getenv("MESHENV_GROUP");
-        const int want = force ? atoi(force) : 16;
+        int want = 1;
+        if (force) want = atoi(force);
+        else if (n_envs <= 256 * 16) {
+            int g = 1;
+            while (g * 2 <= n_envs / 256 && g * 2 <= 16) g *= 2;
+            want = g >= 8 ? g : 1;
+        }
         for (int g : {16, 8, 4})
             if (g <= want && group_lds_bytes(cap, g) <= 150 * 1024) { G = g; break; }
         h->group = G;
@@ -286,6 +295,13 @@ int meshenv_set_stream(MeshEnv *h, void *stream)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->stream = (hipStream_t)stream;
+    return MESHENV_OK;
+}
+
+int meshenv_set_packed_output(MeshEnv *h, float *msg_dev)
+{
+    if (!h) return MESHENV_E_ARG;
+    h->S.msg = msg_dev;
     return MESHENV_OK;
 }
 

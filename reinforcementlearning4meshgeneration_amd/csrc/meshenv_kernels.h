@@ -1142,6 +1142,8 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     wave_sync();
 #endif
     unsigned long long st_valid = 0, st_sum = 0, st_sumv = 0;
+    double last_reward = 0.0;
+    int last_done = 0, last_complete = 0;
     const int T = kMulti ? n_steps : 1;
     for (int t = 0; t < T; t++) {
         if (kMulti && t > 0) {
@@ -1158,12 +1160,17 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
             done[o] = (uint8_t)r.done;
             complete[o] = (uint8_t)r.complete;
         }
+        last_reward = r.reward; last_done = r.done; last_complete = r.complete;
         if (r.done) {
             if (term_obs && c.lane < kObsDim) term_obs[(size_t)env * kObsDim + c.lane] = c.obs;
             if (auto_reset) reset_from_domain(c, S);
         }
     }
     if (c.lane < kObsDim) obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
+    if (S.msg && c.lane < 21) {
+        const float v = c.lane < kObsDim ? c.obs : (c.lane == 18 ? (float)last_reward : (c.lane == 19 ? (float)last_done : (float)last_complete));
+        S.msg[(size_t)env * 21 + c.lane] = v;
+    }
     store_env(c, S);
 #ifdef MESHENV_STAMPS
     // diagnostic build only: per-wave timeline (100 MHz realtime ticks) instead of the work counters
@@ -1220,6 +1227,10 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
         if (auto_reset) reset_from_domain(c, S);
     }
     if (c.lane < kObsDim) obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
+    if (S.msg && c.lane < 21) {  // the exchange message of the multi-GPU path, written in place of separate pack kernels
+        const float v = c.lane < kObsDim ? c.obs : (c.lane == 18 ? (float)r.reward : (c.lane == 19 ? (float)r.done : (float)r.complete));
+        S.msg[(size_t)env * 21 + c.lane] = v;
+    }
     store_env(c, S);
     if (c.lane == 0) {
         EnvCounters k = cnt0;

@@ -72,6 +72,7 @@ struct DevState {
     EnvScalars *scal;         // [E]
     EnvCounters *cnt;         // [E]
     float *obs_cache;         // [E][18] observation of the current state
+    float *msg;               // optional [E][21] packed (obs | reward | done | complete) float32 output, NULL = off
     // ---- logs (generated_meshes / boundary.vertices), optional
     int32_t *log_quads;       // [E][log_cap][4]
     double2 *log_vxy;         // [E][log_cap]

@@ -204,6 +204,17 @@ class MeshVecEnv:
         self._check(rc, "meshenv_rollout")
         return self.obs, reward, done, complete
 
+    def set_packed_output(self, msg):
+        """msg: float32 CUDA tensor [n, 21] (or None) that every following step fills with
+        (obs | reward | done | complete) -- the all_gather payload of the multi-GPU path."""
+        if msg is None:
+            self._check(self._L.meshenv_set_packed_output(self._handle, None), "meshenv_set_packed_output")
+            return
+        t = self._torch
+        if msg.dtype != t.float32 or tuple(msg.shape) != (self.num_envs, 21) or not msg.is_contiguous() or msg.device != self.device:
+            raise ValueError("packed output must be a contiguous float32 CUDA tensor [n_envs, 21]")
+        self._check(self._L.meshenv_set_packed_output(self._handle, C.c_void_p(msg.data_ptr())), "meshenv_set_packed_output")
+
     def status(self):
         self._bind_stream()
         self._check(self._L.meshenv_get_status(self._handle, self._status.data_ptr()), "meshenv_get_status")
