@@ -223,8 +223,10 @@ def main():
         traffic, traffic_src = pmc_traffic(n)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                           "kernel": "meshenv::k_step", "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": float(np.min(kt)) * 1e3,
-                           "algorithmic_bytes_per_launch": alg, "launches_timed": int(len(kt))}
+                           "kernel": ("meshenv::k_step_group<%d>" % env.group_size) if env.group_size > 1 else "meshenv::k_step<false>",
+                           "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": float(np.min(kt)) * 1e3,
+                           "algorithmic_bytes_per_launch": alg, "launches_timed": int(len(kt)) * args.time_every,
+                           "timing": "HIP events on the launch stream bracketing groups of %d consecutive launches" % args.time_every}
     env.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, seed=99)

@@ -109,6 +109,9 @@ int meshenv_set_stream(MeshEnv *h, void *stream);
 
 int meshenv_num_envs(const MeshEnv *h);
 int meshenv_max_ring(const MeshEnv *h);
+/* Environments per workgroup of the single-step kernel: 1 = k_step<false> (one wave per workgroup), 8 / 16 =
+ * k_step_group<G> (chosen at creation from n_envs, see meshenv_create in csrc/meshenv_hip.hip). */
+int meshenv_group_size(const MeshEnv *h);
 
 /*
  * reset(): rl/boundary_env.py:67-84 for every env whose mask byte is non-zero (all envs when
@@ -186,13 +189,14 @@ int meshenv_get_elements(MeshEnv *h, int env, int32_t *quads_host, int cap_elems
 int meshenv_counters(MeshEnv *h, uint64_t *out_host);
 
 /*
- * Per-launch kernel timing with HIP events recorded on the handle's stream around every
- * meshenv_step / meshenv_rollout launch (bench.py's roofline figure).  meshenv_set_timing(h, k)
- * with k > 0 times every k-th launch (an event pair costs ~8 us of stream time per launch on this stack, so
- * k = 1 slows a launch-bound loop down; bench.py samples), k = 0 switches timing off.  Arming creates
- * a pool of MESHENV_TIMING_POOL event pairs and clears the record; meshenv_kernel_times()
- * synchronises and copies the durations (milliseconds, launch order) of the launches recorded since
- * then -- at most the newest MESHENV_TIMING_POOL of them -- into ms_host[cap] and clears the record.
+ * Kernel timing with HIP events on the handle's stream (bench.py's roofline figure).  meshenv_set_timing(h, k),
+ * k > 0: every other group of k consecutive meshenv_step / meshenv_rollout launches is bracketed by one event pair
+ * and reported as (elapsed / k), the average launch duration inside the group including the launch-to-launch gap
+ * (an event pair costs several microseconds of stream time on this stack, so bracketing single ~20 us launches would
+ * both slow the loop and inflate the figure).  k = 0 switches timing off.  Arming creates a pool of
+ * MESHENV_TIMING_POOL event pairs and clears the record; meshenv_kernel_times() synchronises and copies the
+ * per-launch averages (milliseconds, in launch order) of the groups recorded since then -- at most the newest
+ * MESHENV_TIMING_POOL -- into ms_host[cap] and clears the record.  Call it before changing k.
  */
 #define MESHENV_TIMING_POOL 4096
 int meshenv_set_timing(MeshEnv *h, int enable);

@@ -33,7 +33,7 @@ _lib = None
 # every symbol include/meshenv.h declares
 EXPORTS = [
     "meshenv_default_params", "meshenv_abi_version", "meshenv_device_count", "meshenv_create", "meshenv_destroy",
-    "meshenv_last_error", "meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_reset",
+    "meshenv_last_error", "meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_group_size", "meshenv_reset",
     "meshenv_step", "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",
     "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times", "meshenv_selftest", "meshenv_set_packed_output",
 ]
@@ -65,6 +65,8 @@ def load():
     L.meshenv_set_stream.argtypes = [vp, vp]
     L.meshenv_num_envs.argtypes = [vp]
     L.meshenv_max_ring.argtypes = [vp]
+    L.meshenv_group_size.argtypes = [vp]
+    L.meshenv_group_size.restype = C.c_int
     L.meshenv_reset.argtypes = [vp, u8p, f32p]
     L.meshenv_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.meshenv_rollout.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]

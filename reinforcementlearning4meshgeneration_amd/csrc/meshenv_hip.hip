@@ -33,7 +33,7 @@ struct MeshEnv {
     std::vector<int32_t> dom_off_host, env_dom_host;
     std::vector<void *> allocs;
     std::string err;
-    int timing = 0;              // 0 = off, k = record every k-th launch
+    int timing = 0;              // 0 = off, k = bracket every other group of k consecutive launches
     long long launch_count = 0;
     std::vector<hipEvent_t> ev;  // 2 * MESHENV_TIMING_POOL events, created on first use
     long long ev_count = 0;      // launches recorded since timing was armed
@@ -307,6 +307,7 @@ int meshenv_set_packed_output(MeshEnv *h, float *msg_dev)
 
 int meshenv_num_envs(const MeshEnv *h) { return h ? h->n_envs : MESHENV_E_ARG; }
 int meshenv_max_ring(const MeshEnv *h) { return h ? h->max_ring : MESHENV_E_ARG; }
+int meshenv_group_size(const MeshEnv *h) { return h ? h->group : MESHENV_E_ARG; }
 
 int meshenv_reset(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev)
 {
@@ -323,8 +324,8 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
     if (!actions_dev || !obs_dev || !reward_dev || !done_dev || !complete_dev) return fail_arg(h, "meshenv_step: null device pointer");
     if (n_steps <= 0) return fail_arg(h, "meshenv_rollout: n_steps must be positive");
     const size_t slot = (size_t)(h->ev_count % MESHENV_TIMING_POOL);
-    const bool timed = h->timing > 0 && (h->launch_count++ % h->timing) == 0;
-    if (timed) HIP_TRY(h, hipEventRecord(h->ev[2 * slot], h->stream));
+    const long long pos = h->timing > 0 ? (h->launch_count++ % (2LL * h->timing)) : -1;
+    if (pos == 0) HIP_TRY(h, hipEventRecord(h->ev[2 * slot], h->stream));
     if (n_steps == 1 && h->group > 1) {
         const int G = h->group;
         const dim3 grid((h->n_envs + G - 1) / G), block(64 * G);
@@ -344,7 +345,7 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         hipLaunchKernelGGL(k_step<true>, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, n_steps, actions_dev, obs_dev,
                            reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
     HIP_TRY(h, hipGetLastError());
-    if (timed) {
+    if (pos >= 0 && pos == h->timing - 1) {
         HIP_TRY(h, hipEventRecord(h->ev[2 * slot + 1], h->stream));
         h->ev_count += 1;
     }
@@ -564,6 +565,7 @@ int meshenv_kernel_times(MeshEnv *h, float *ms_host, int cap, int32_t *n_out)
     for (long long k = 0; k < have; k++) {
         const size_t slot = (size_t)((first + k) % MESHENV_TIMING_POOL);
         HIP_TRY(h, hipEventElapsedTime(ms_host + k, h->ev[2 * slot], h->ev[2 * slot + 1]));
+        ms_host[k] /= (float)(h->timing > 0 ? h->timing : 1);
     }
     *n_out = (int32_t)have;
     h->ev_count = 0;

@@ -1113,7 +1113,7 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
 // every lane predicate and table of the step body into the loop preheader (hundreds of instructions and SGPR
 // spills that a single step would pay for nothing).
 #ifndef MESHENV_STEP_WAVES_PER_SIMD
-#define MESHENV_STEP_WAVES_PER_SIMD 2
+#define MESHENV_STEP_WAVES_PER_SIMD 4
 #endif
 template <bool kMulti>
 __global__ void __launch_bounds__(64, MESHENV_STEP_WAVES_PER_SIMD)

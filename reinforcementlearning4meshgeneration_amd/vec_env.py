@@ -126,6 +126,7 @@ class MeshVecEnv:
             msg = self._L.meshenv_last_error(None)
             raise _capi.MeshEnvError(f"meshenv_create failed (code {rc}): {msg.decode() if msg else ''}")
         self.max_ring = self._L.meshenv_max_ring(self._handle)
+        self.group_size = self._L.meshenv_group_size(self._handle)
         n = self.num_envs
         self.obs = torch.zeros((n, OBS_DIM), dtype=torch.float32, device=self.device)
         self.terminal_obs = torch.zeros((n, OBS_DIM), dtype=torch.float32, device=self.device)
@@ -262,7 +263,8 @@ class MeshVecEnv:
         return dict(steps=int(out[0]), valid=int(out[1]), sum_ring=int(out[2]), sum_ring_valid=int(out[3]))
 
     def set_timing(self, every: int):
-        """Time every `every`-th step/rollout launch with HIP events (0 / False = off)."""
+        """Bracket every other group of `every` consecutive step/rollout launches with HIP events (0 = off);
+        kernel_times_ms() then returns the per-launch average of each bracketed group."""
         self._check(self._L.meshenv_set_timing(self._handle, int(every)), "meshenv_set_timing")
 
     def kernel_times_ms(self) -> np.ndarray:
