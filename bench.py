@@ -92,6 +92,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--workload", default="boundary0", choices=["boundary0", "d1", "mixed", "random"],
+                    help="boundary0 = the headline config (BASELINE.json configs[1]); d1 = boundary16 (120-vertex ring, "
+                         "configs[2] domain); mixed = d1/d2/d3 interleaved (configs[3] shape); random = one "
+                         "GenerateRandomPolygon-style ring per env (configs[4] shape).  Domain coordinates of d1/d2/d3 "
+                         "come from tests/golden (data recorded from the reference's ui/domains files)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-every", type=int, default=8, help="N > 1: steps per all-gather bucket")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
@@ -127,7 +132,22 @@ def main():
     torch.cuda.set_device(dev)
 
     n, K, W = args.envs, args.steps, args.warmup
-    env = MeshVecEnv([boundary(0)], n_envs=n, device=local_rank, auto_reset=True, log_capacity=0)
+    def golden_domain(name):
+        tr = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        return [tuple(p) for p in tr["domain_xy"]]
+
+    if args.workload == "boundary0":
+        doms, env_domain, wl = [boundary(0)], None, "boundary() (general/polygon.py:79-83, 30-vertex ring)"
+    elif args.workload == "d1":
+        doms, env_domain, wl = [golden_domain("boundary16_biased_s2")], None, "ui/domains/boundary16.json (d1, 120-vertex ring)"
+    elif args.workload == "mixed":
+        doms = [golden_domain(x) for x in ("boundary16_biased_s2", "boundary15_biased_s5", "test1_biased_s42")]
+        env_domain, wl = np.arange(n, dtype=np.int32) % 3, "d1/d2/d3 interleaved (120/196/272-vertex rings)"
+    else:
+        from reinforcementlearning4meshgeneration_amd.domains import random_domain
+        doms = [random_domain(1000 + rank * n + k) for k in range(n)]
+        env_domain, wl = np.arange(n, dtype=np.int32), "one random star-shaped ring per env (GenerateRandomPolygon restated, densified)"
+    env = MeshVecEnv(doms, n_envs=n, env_domain=env_domain, device=local_rank, auto_reset=True, log_capacity=0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     lo = torch.tensor([-1.0, -1.5, 0.0], device=dev)
@@ -210,7 +230,7 @@ def main():
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{n} vectorised boundary() envs per GPU (general/polygon.py:79-83, 30-vertex ring), "
+        "config": {"workload": f"{n} vectorised envs per GPU on {wl}, "
                                "uniform-random float32 actions resident in HBM, auto-reset, one meshenv_step launch "
                                "per vector step" + (f", + one async RCCL all-gather per {GS} steps of the [{GS},n,21] f32 obs/reward/done bucket written by the kernel" if world > 1 else ""),
                    "n_envs_per_gpu": n, "n_envs_total": n * world, "parallelism": f"env-shard x{world}",

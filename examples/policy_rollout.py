@@ -1,0 +1,104 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[2]: 4096 envs of ui/domains/boundary16.json (d1) on one MI355X with an SB3-SAC-shaped
+policy in the loop, everything on the GPU (no numpy hop).
+
+The actor is the reference's architecture (rl/baselines/RL_Mesh.py:183-196: MlpPolicy, ReLU, net_arch [128, 128, 128];
+SAC's squashed-Gaussian actor: mean and log_std heads, tanh squash, rescale to the action Box), random-initialised with
+seed 999 -- SB3 itself is not installed in this image and there is no checkpoint to load.
+
+    python examples/policy_rollout.py [--envs 4096] [--steps 300] [--domain d1|boundary0]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--domain", default="d1", choices=["d1", "boundary0"])
+    ap.add_argument("--deterministic", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run the actor eagerly instead of as one captured HIP graph")
+    args = ap.parse_args()
+    import torch
+
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv, boundary
+    from reinforcementlearning4meshgeneration_amd.vec_env import ACTION_HIGH, ACTION_LOW
+
+    if args.domain == "d1":
+        tr = np.load(os.path.join(ROOT, "tests", "golden", "boundary16_biased_s2.npz"))
+        dom = [tuple(p) for p in tr["domain_xy"]]
+    else:
+        dom = boundary(0)
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(999)
+    trunk = torch.nn.Sequential(torch.nn.Linear(18, 128), torch.nn.ReLU(), torch.nn.Linear(128, 128), torch.nn.ReLU(),
+                                torch.nn.Linear(128, 128), torch.nn.ReLU()).to(dev)
+    mu_head, log_std_head = torch.nn.Linear(128, 3).to(dev), torch.nn.Linear(128, 3).to(dev)
+    low = torch.as_tensor(ACTION_LOW, device=dev)
+    high = torch.as_tensor(ACTION_HIGH, device=dev)
+
+    @torch.no_grad()
+    def act(obs):
+        h = trunk(obs)
+        mu = mu_head(h)
+        if not args.deterministic:
+            std = log_std_head(h).clamp(-20, 2).exp()
+            mu = mu + std * torch.randn_like(mu)          # default generator: capturable in a HIP graph
+        a = torch.tanh(mu)                                 # SB3 squashes, then unscale_action maps [-1, 1] -> Box
+        return (low + 0.5 * (a + 1.0) * (high - low)).contiguous()
+
+    env = MeshVecEnv([dom], n_envs=args.envs, device=0)
+    obs = env.reset()          # env.obs: the kernel always writes observations into this tensor
+    if not args.no_graph:
+        # ~25 tiny launches of the actor -> one graph replay; input = the env's observation buffer, output static
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                static_act = act(env.obs)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_act = act(env.obs)
+
+        def policy(_obs):
+            graph.replay()
+            return static_act
+    else:
+        policy = act
+    ep_done = torch.zeros((), dtype=torch.int64, device=dev)
+    ep_complete = torch.zeros((), dtype=torch.int64, device=dev)
+    rew_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    for t in range(args.warmup + args.steps):
+        if t == args.warmup:
+            torch.cuda.synchronize()
+            c0 = env.counters()
+            t0 = time.perf_counter()
+        obs, rew, done, comp = env.step(policy(obs))
+        ep_done += done.sum()
+        ep_complete += (done & comp).sum()
+        rew_sum += rew.sum()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c1 = env.counters()
+    steps = c1["steps"] - c0["steps"]
+    print(json.dumps({"workload": f"{args.envs} envs, domain {args.domain} ({len(dom)}-vertex ring), SAC-shaped MLP actor 18-128-128-128-3 on the same GPU",
+                      "env_steps_per_s": steps / dt, "us_per_vector_step": 1e6 * dt / args.steps,
+                      "valid_action_rate": (c1["valid"] - c0["valid"]) / steps,
+                      "episodes_finished": int(ep_done), "episodes_completed": int(ep_complete),
+                      "mean_reward": float(rew_sum) / ((args.warmup + args.steps) * args.envs)}))
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

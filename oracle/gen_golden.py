@@ -118,8 +118,30 @@ def save(name, tr):
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def export_fixture():
+    """The .inp text the reference writes for the first completed episode of the boundary0_uniform_s7 stream."""
+    import contextlib, io, json, tempfile
+    pts = H.domain_points("boundary0")
+    acts = H.uniform_actions(7, 1500)
+    env = H.make_env(pts)
+    env.reset()
+    for t in range(len(acts)):
+        _, _, done, info = env.step(acts[t])
+        if done and info["is_complete"]:
+            with tempfile.NamedTemporaryFile("r", suffix=".inp") as f, contextlib.redirect_stdout(io.StringIO()):
+                env.write_generated_elements_2_file(f.name)
+                text = open(f.name).read()
+            json.dump({"trace": "boundary0_uniform_s7", "step": t, "n_elements": len(env.generated_meshes), "inp": text},
+                      open(os.path.join(OUT, "inp_boundary0_uniform_s7.json"), "w"))
+            print(f"inp fixture: step {t}, {len(env.generated_meshes)} elements, {len(text)} bytes")
+            return
+        if done:
+            env.reset()
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    export_fixture()
     for name, dom, kind, seed, T in TRACES:
         pts = H.domain_points(dom)
         acts = (H.uniform_actions if kind == "uniform" else H.biased_actions)(seed, T)

@@ -206,6 +206,7 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
         }
         for (int g : {16, 8, 4})
             if (g <= want && group_lds_bytes(cap, g) <= 150 * 1024) { G = g; break; }
+        if (!force && (G < 8 || n_envs > 256 * G)) G = 1;  // LDS forced a smaller group: more than one workgroup per CU
         h->group = G;
         h->group_lds = group_lds_bytes(cap, G);
         if (G > 1 && h->group_lds > 64 * 1024) {

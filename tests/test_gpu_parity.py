@@ -181,3 +181,26 @@ def test_mixed_ragged_domains(torch_cuda):
     a[pick] = b[pick]
     st = _run_lockstep(torch_cuda, doms, env_domain, a.astype(np.float32), check_every=50, sample=256)
     print("mixed:", st)
+
+
+def test_group_kernel_on_long_ragged_rings(torch_cuda, monkeypatch):
+    """The CU-group kernel (G = 8: LDS-limited) on BASELINE.json configs[3]-style mixed d1/d2/d3 domains
+    (120 / 196 / 272-vertex rings, several 64-lane chunks per pass) against the oracle."""
+    doms = []
+    for name in ("boundary16_biased_s2", "boundary15_biased_s5", "test1_biased_s42"):
+        tr = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        doms.append([tuple(p) for p in tr["domain_xy"]])
+    n, T = 2048, 48
+    env_domain = (np.arange(n) % 3).astype(np.int32)
+    rng = np.random.default_rng(11)
+    a = rng.uniform([-1, -1.5, 0], [1, 1.5, 1.5], size=(T, n, 3))
+    pick = rng.random((T, n)) < 0.6
+    b = np.stack([rng.uniform(-1, 1, (T, n)), rng.uniform(0.2, 1.0, (T, n)), rng.uniform(0.3, 1.2, (T, n))], axis=2)
+    a[pick] = b[pick]
+    from reinforcementlearning4meshgeneration_amd.vec_env import MeshVecEnv
+    probe = MeshVecEnv(doms, env_domain=env_domain)
+    assert probe.group_size == 8 and probe.max_ring == 272
+    probe.close()
+    st = _run_lockstep(torch_cuda, doms, env_domain, a.astype(np.float32), check_every=16, sample=96)
+    print("group/ragged:", st)
+    assert st["valid"] > 0.1 * n * T
