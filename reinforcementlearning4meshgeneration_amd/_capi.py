@@ -45,6 +45,13 @@ def load():
     if _lib is not None:
         return _lib
     path = os.environ.get("MESHENV_LIB", LIB_PATH)  # A/B builds of the same library
+    if not os.path.exists(path) and path == LIB_PATH:
+        try:  # a fresh checkout: compile the library in-tree (needs hipcc); never a substitute implementation
+            from .build import build
+            build(force=True)
+        except Exception as exc:
+            raise MeshEnvError(f"{LIB_PATH} is missing and could not be built ({exc}); this package has no CPU "
+                               "fallback") from exc
     if not os.path.exists(path):
         raise MeshEnvError(
             f"{path} is missing: build it with `python -m reinforcementlearning4meshgeneration_amd.build` "
