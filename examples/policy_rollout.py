@@ -27,7 +27,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--domain", default="d1", choices=["d1", "boundary0"])
     ap.add_argument("--deterministic", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="run the actor eagerly instead of as one captured HIP graph")
+    ap.add_argument("--actor", default="fused", choices=["fused", "graph", "eager"],
+                    help="fused = the hand-written HIP actor kernel (one launch); graph = the torch MLP captured as one HIP "
+                         "graph; eager = the torch MLP launch by launch")
     args = ap.parse_args()
     import torch
 
@@ -59,7 +61,15 @@ def main():
 
     env = MeshVecEnv([dom], n_envs=args.envs, device=0)
     obs = env.reset()          # env.obs: the kernel always writes observations into this tensor
-    if not args.no_graph:
+    if args.actor == "fused":
+        from reinforcementlearning4meshgeneration_amd.actor import FusedActor
+        fused = FusedActor.from_torch([trunk[0], trunk[2], trunk[4]], mu_head, log_std_head)
+        actions = torch.empty((args.envs, 3), dtype=torch.float32, device=dev)
+        noise = torch.empty((args.envs, 3), dtype=torch.float32, device=dev)
+
+        def policy(o):
+            return fused.forward(o, None if args.deterministic else noise.normal_(), out=actions)
+    elif args.actor == "graph":
         # ~25 tiny launches of the actor -> one graph replay; input = the env's observation buffer, output static
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -76,27 +86,30 @@ def main():
             return static_act
     else:
         policy = act
-    ep_done = torch.zeros((), dtype=torch.int64, device=dev)
-    ep_complete = torch.zeros((), dtype=torch.int64, device=dev)
-    rew_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    # timed loop: policy + step only (two or three launches per vector step)
     for t in range(args.warmup + args.steps):
         if t == args.warmup:
             torch.cuda.synchronize()
             c0 = env.counters()
             t0 = time.perf_counter()
         obs, rew, done, comp = env.step(policy(obs))
-        ep_done += done.sum()
-        ep_complete += (done & comp).sum()
-        rew_sum += rew.sum()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c1 = env.counters()
     steps = c1["steps"] - c0["steps"]
-    print(json.dumps({"workload": f"{args.envs} envs, domain {args.domain} ({len(dom)}-vertex ring), SAC-shaped MLP actor 18-128-128-128-3 on the same GPU",
+    # untimed: episode statistics over a few more steps (each reduction is a launch of its own)
+    ep_done = ep_complete = 0
+    rew_sum = 0.0
+    for t in range(50):
+        obs, rew, done, comp = env.step(policy(obs))
+        ep_done += int(done.sum())
+        ep_complete += int((done & comp).sum())
+        rew_sum += float(rew.sum())
+    print(json.dumps({"workload": f"{args.envs} envs, domain {args.domain} ({len(dom)}-vertex ring), SAC-shaped MLP actor 18-128-128-128-3 on the same GPU, actor = " + args.actor,
                       "env_steps_per_s": steps / dt, "us_per_vector_step": 1e6 * dt / args.steps,
                       "valid_action_rate": (c1["valid"] - c0["valid"]) / steps,
-                      "episodes_finished": int(ep_done), "episodes_completed": int(ep_complete),
-                      "mean_reward": float(rew_sum) / ((args.warmup + args.steps) * args.envs)}))
+                      "episodes_finished_per_1000_env_steps": 1000.0 * ep_done / (50 * args.envs),
+                      "completed_fraction": ep_complete / max(1, ep_done), "mean_reward": rew_sum / (50 * args.envs)}))
     env.close()
 
 

@@ -203,6 +203,23 @@ int meshenv_set_timing(MeshEnv *h, int enable);
 int meshenv_kernel_times(MeshEnv *h, float *ms_host, int cap, int32_t *n_out);
 
 /*
+ * Fused SAC actor forward -- the caller of the hot path, not part of the environment.
+ * Architecture fixed to the reference's policy (rl/baselines/RL_Mesh.py:183-196: MlpPolicy, ReLU,
+ * net_arch [128, 128, 128]; SB3's squashed-Gaussian actor): latent = MLP(obs[18]); mean / log_std = Linear(latent);
+ * action = low + 0.5 * (tanh(mean + exp(clamp(log_std, -20, 2)) * noise) + 1) * (high - low); noise_dev = NULL gives
+ * the deterministic action.  One launch instead of ~25, so obs -> action -> step stays on the GPU.
+ * Weights: host pointers in torch.nn.Linear layout ([out][in], row-major), float32.
+ */
+typedef struct MeshActor MeshActor;
+int meshenv_actor_create(int device, void *stream, MeshActor **out);
+void meshenv_actor_destroy(MeshActor *a);
+int meshenv_actor_set_stream(MeshActor *a, void *stream);
+int meshenv_actor_load(MeshActor *a, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                       const float *b3, const float *w_mu, const float *b_mu, const float *w_log_std,
+                       const float *b_log_std, const float *low, const float *high);
+int meshenv_actor_forward(MeshActor *a, int n, const float *obs_dev, const float *noise_dev, float *actions_dev);
+
+/*
  * Test hook: evaluate one device geometry primitive on n items (in_per_item doubles each) and copy the results
  * back, so the parity tests can compare the device primitives with the oracle's one by one.
  *   what 0 round(python float, 4)   1 round(np.float64, 4)   2 Vertex.to_find_clockwise_angle (6 doubles: s, p1, p2)

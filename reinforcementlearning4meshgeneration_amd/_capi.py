@@ -36,6 +36,8 @@ EXPORTS = [
     "meshenv_last_error", "meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_group_size", "meshenv_reset",
     "meshenv_step", "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",
     "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times", "meshenv_selftest", "meshenv_set_packed_output",
+    "meshenv_actor_create", "meshenv_actor_destroy", "meshenv_actor_set_stream", "meshenv_actor_load",
+    "meshenv_actor_forward",
 ]
 
 
@@ -87,6 +89,14 @@ def load():
     L.meshenv_selftest.restype = C.c_int
     L.meshenv_set_packed_output.argtypes = [vp, vp]
     L.meshenv_set_packed_output.restype = C.c_int
+    L.meshenv_actor_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.meshenv_actor_destroy.argtypes = [vp]
+    L.meshenv_actor_destroy.restype = None
+    L.meshenv_actor_set_stream.argtypes = [vp, vp]
+    L.meshenv_actor_load.argtypes = [vp] + [vp] * 12
+    L.meshenv_actor_forward.argtypes = [vp, C.c_int, vp, vp, vp]
+    for name in ("meshenv_actor_create", "meshenv_actor_set_stream", "meshenv_actor_load", "meshenv_actor_forward"):
+        getattr(L, name).restype = C.c_int
     for name in ("meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_reset", "meshenv_step",
                  "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",
                  "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times"):

@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "meshenv_actor.h"
 #include "meshenv_kernels.h"
 
 using namespace meshenv;
@@ -570,6 +571,118 @@ int meshenv_kernel_times(MeshEnv *h, float *ms_host, int cap, int32_t *n_out)
     }
     *n_out = (int32_t)have;
     h->ev_count = 0;
+    return MESHENV_OK;
+}
+
+// ------------------------------------------------------------------------------------------ fused SAC actor
+struct MeshActor {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float *buf = nullptr;  // all weights, one allocation
+    ActorWeights W{};
+    bool loaded = false;
+    std::string err;
+};
+
+int meshenv_actor_create(int device, void *stream, MeshActor **out)
+{
+    if (!out) return MESHENV_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        g_create_error = "meshenv_actor_create: no such HIP device";
+        return MESHENV_E_HIP;
+    }
+    MeshActor *a = new MeshActor();
+    a->device = device;
+    a->stream = (hipStream_t)stream;
+    const size_t nfloat = (size_t)kActIn * kActHid + kActHid + 2 * ((size_t)kActHid * kActHid + kActHid) + (size_t)kActHid * 8 + 8;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&a->buf, nfloat * sizeof(float)) != hipSuccess) {
+        g_create_error = "meshenv_actor_create: hipMalloc failed";
+        delete a;
+        return MESHENV_E_HIP;
+    }
+    *out = a;
+    return MESHENV_OK;
+}
+
+void meshenv_actor_destroy(MeshActor *a)
+{
+    if (!a) return;
+    (void)hipSetDevice(a->device);
+    (void)hipStreamSynchronize(a->stream);
+    if (a->buf) (void)hipFree(a->buf);
+    delete a;
+}
+
+int meshenv_actor_set_stream(MeshActor *a, void *stream)
+{
+    if (!a) return MESHENV_E_ARG;
+    a->stream = (hipStream_t)stream;
+    return MESHENV_OK;
+}
+
+// weights in torch.nn.Linear layout ([out][in], row-major), host pointers
+int meshenv_actor_load(MeshActor *a, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                       const float *b3, const float *w_mu, const float *b_mu, const float *w_log_std,
+                       const float *b_log_std, const float *low, const float *high)
+{
+    if (!a || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w_mu || !b_mu || !w_log_std || !b_log_std || !low || !high)
+        return MESHENV_E_ARG;
+    std::vector<float> h;
+    auto transposed = [&](const float *w, int out, int in, int out_pad) {  // [out][in] -> [in][out_pad]
+        const size_t off = h.size();
+        h.resize(off + (size_t)in * out_pad, 0.0f);
+        for (int o = 0; o < out; o++)
+            for (int k = 0; k < in; k++) h[off + (size_t)k * out_pad + o] = w[(size_t)o * in + k];
+        return off;
+    };
+    auto plain = [&](const float *b, int n, int pad) {
+        const size_t off = h.size();
+        h.resize(off + pad, 0.0f);
+        for (int i = 0; i < n; i++) h[off + i] = b[i];
+        return off;
+    };
+    const size_t o_w1 = transposed(w1, kActHid, kActIn, kActHid), o_b1 = plain(b1, kActHid, kActHid);
+    const size_t o_w2 = transposed(w2, kActHid, kActHid, kActHid), o_b2 = plain(b2, kActHid, kActHid);
+    const size_t o_w3 = transposed(w3, kActHid, kActHid, kActHid), o_b3 = plain(b3, kActHid, kActHid);
+    const size_t o_wh = h.size();
+    h.resize(o_wh + (size_t)kActHid * 8, 0.0f);
+    for (int k = 0; k < kActHid; k++)
+        for (int o = 0; o < 3; o++) {
+            h[o_wh + (size_t)k * 8 + o] = w_mu[(size_t)o * kActHid + k];
+            h[o_wh + (size_t)k * 8 + 3 + o] = w_log_std[(size_t)o * kActHid + k];
+        }
+    const size_t o_bh = h.size();
+    h.resize(o_bh + 8, 0.0f);
+    for (int o = 0; o < 3; o++) { h[o_bh + o] = b_mu[o]; h[o_bh + 3 + o] = b_log_std[o]; }
+    if (hipSetDevice(a->device) != hipSuccess ||
+        hipMemcpy(a->buf, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        a->err = "meshenv_actor_load: upload failed";
+        return MESHENV_E_HIP;
+    }
+    a->W.w1t = a->buf + o_w1; a->W.b1 = a->buf + o_b1;
+    a->W.w2t = a->buf + o_w2; a->W.b2 = a->buf + o_b2;
+    a->W.w3t = a->buf + o_w3; a->W.b3 = a->buf + o_b3;
+    a->W.wht = a->buf + o_wh; a->W.bh = a->buf + o_bh;
+    for (int i = 0; i < 3; i++) { a->W.low[i] = low[i]; a->W.high[i] = high[i]; }
+    a->loaded = true;
+    return MESHENV_OK;
+}
+
+int meshenv_actor_forward(MeshActor *a, int n, const float *obs_dev, const float *noise_dev, float *actions_dev)
+{
+    if (!a || n <= 0 || !obs_dev || !actions_dev) return MESHENV_E_ARG;
+    if (!a->loaded) {
+        a->err = "meshenv_actor_forward: no weights loaded";
+        return MESHENV_E_STATE;
+    }
+    hipLaunchKernelGGL(k_actor_forward, dim3((n + kActEnvs - 1) / kActEnvs), dim3(256), 0, a->stream, a->W, n, obs_dev, noise_dev,
+                       actions_dev);
+    if (hipGetLastError() != hipSuccess) {
+        a->err = "meshenv_actor_forward: launch failed";
+        return MESHENV_E_HIP;
+    }
     return MESHENV_OK;
 }
 
