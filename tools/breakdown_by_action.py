@@ -1,6 +1,6 @@
 """Dev tool: kernel time by action mix (GPU)."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reinforcementlearning4meshgeneration_amd.vec_env import MeshVecEnv
 from reinforcementlearning4meshgeneration_amd.domains import boundary, read_polygon
 n=4096; T=120

@@ -1,8 +1,8 @@
 """Dev tool: timeline of the CU-group kernel (diagnostic build)."""
 import os, sys, ctypes as C, numpy as np, torch
-os.environ["MESHENV_LIB"]=os.path.join(os.path.dirname(os.path.abspath(__file__)),"build_variants/dbg_stamps.so")
+os.environ["MESHENV_LIB"]=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),"build_variants/dbg_stamps.so")
 os.environ["MESHENV_GROUP"]="16"
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reinforcementlearning4meshgeneration_amd.vec_env import MeshVecEnv
 from reinforcementlearning4meshgeneration_amd.domains import boundary
 n=4096

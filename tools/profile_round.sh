@@ -2,7 +2,7 @@
 # Collects the round's profile artefacts on the GPU box into gpurun_out/prof_<tag>/ (copy the summaries to profiles/).
 tag=${1:-r01}
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp

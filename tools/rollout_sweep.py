@@ -1,6 +1,6 @@
 """Dev tool: per-step time of the fused rollout kernel vs single-step launches."""
 import os, sys, numpy as np, torch, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reinforcementlearning4meshgeneration_amd.vec_env import MeshVecEnv
 from reinforcementlearning4meshgeneration_amd.domains import boundary
 n=4096

@@ -1,7 +1,7 @@
 """Dev tool: per-wave timeline of one k_step launch (diagnostic build with -DMESHENV_STAMPS)."""
 import os, sys, ctypes as C, numpy as np, torch
-os.environ["MESHENV_LIB"]=os.path.join(os.path.dirname(os.path.abspath(__file__)),"build_variants/dbg_stamps.so")
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+os.environ["MESHENV_LIB"]=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),"build_variants/dbg_stamps.so")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reinforcementlearning4meshgeneration_amd.vec_env import MeshVecEnv
 from reinforcementlearning4meshgeneration_amd.domains import boundary
 n=int(sys.argv[1]) if len(sys.argv)>1 else 4096
