@@ -1245,7 +1245,7 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
 //
 // Why: ~12 % of the steps extract an element and take ~4x longer than a rejected action; with one wave per
 // workgroup those long waves land on SIMDs at random, and the launch ends with the SIMD that happens to hold three or
-// four of them (measured: 12.2 us alone on a SIMD, 13.3 / 14.8 / 16.8 us with 2 / 3 / 4 -- profiles/, tools_stamps.py).
+// four of them (measured: 12.2 us alone on a SIMD, 13.3 / 14.8 / 16.8 us with 2 / 3 / 4 -- profiles/, tools/stamps_timeline.py).
 // Here every wave runs the CHECKS of its own env (phase 1), the workgroup meets at one barrier, and the pending
 // UPDATES are dealt round-robin over the four SIMDs of the CU (phase 2): wave (simd s, r-th on that SIMD) takes the
 // (4r+s)-th pending env of the group.  The env's ring never moves -- it is already in the workgroup's LDS -- only
