@@ -247,6 +247,17 @@ def main():
                            "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": float(np.min(kt)) * 1e3,
                            "algorithmic_bytes_per_launch": alg, "launches_timed": int(len(kt)) * args.time_every,
                            "timing": "HIP events on the launch stream bracketing groups of %d consecutive launches" % args.time_every}
+    if world == 1 and args.workload == "boundary0":
+        # informational: the same steps fused T per launch (meshenv_rollout, open-loop actions); never part of `value`
+        Tr = min(64, K + W)
+        env.rollout(actions[:Tr])
+        torch.cuda.synchronize()
+        tr0 = time.perf_counter()
+        for _ in range(3):
+            env.rollout(actions[:Tr])
+        torch.cuda.synchronize()
+        out["fused_rollout"] = {"value": 3 * Tr * n / (time.perf_counter() - tr0), "unit": "env-steps/s", "steps_per_launch": Tr,
+                                "note": "meshenv_rollout: T consecutive steps per kernel launch, open-loop only"}
     env.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, seed=99)

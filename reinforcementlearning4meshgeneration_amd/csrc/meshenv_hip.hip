@@ -369,7 +369,7 @@ int meshenv_rollout(MeshEnv *h, int n_steps, const float *actions_dev, float *ob
 __global__ void k_status(DevState S, uint8_t *out)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < S.n_envs) out[e] = (uint8_t)S.scal[e].status;
+    if (e < S.n_envs) out[e] = (uint8_t)(S.scal[e].status & 3);  // public MESHENV_ST_* bits only
 }
 
 int meshenv_get_status(MeshEnv *h, uint8_t *status_dev)
@@ -417,7 +417,7 @@ int meshenv_get_state(MeshEnv *h, int env, int32_t *ring_ids_host, double *ring_
         scalars_host[2] = s.n_elem;
         scalars_host[3] = s.failed;
         scalars_host[4] = n0 + s.n_new;
-        scalars_host[5] = s.status;
+        scalars_host[5] = s.status & 3;
         scalars_host[6] = s.dom;
         scalars_host[7] = n0;
     }

@@ -23,6 +23,10 @@ namespace meshenv {
 
 constexpr int kStNoReference = 1;
 constexpr int kStLogOverflow = 2;
+// internal memo bits: the rule -1 / rule +1 quad of the CURRENT state is known to be rejected (quad validity and the
+// boundary intersection test are pure functions of the state, so a repeated attempt needs no geometry at all);
+// cleared whenever the state changes (extraction, reset)
+constexpr int kStRm1Bad = 4, kStRp1Bad = 8;
 constexpr int kNewBit = 0x40000000;  // ring_id of the k-th vertex created this episode = kNewBit | k
 
 // scratch area appended to the LDS ring arrays
@@ -822,6 +826,10 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
         if (same) rule = -1;  // existing point: the rule -1 quad, B:168-175 (its own filter pass follows)
         else { new_vertex = true; have_filter = true; }
     }
+    if (!new_vertex && (c.status & (rule == -1 ? kStRm1Bad : kStRp1Bad))) {
+        d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;  // B:248, outcome remembered from an earlier attempt on this state
+        return d;
+    }
     if (new_vertex) {  // [new, i-1, i, i+1], B:177-182
         mp0 = -1; mp1 = wrapi(index - 1, n); mp2 = index; mp3 = wrapi(index + 1, n); r = 2;
     } else if (rule == -1) {  // [i-1, i, i+1, i+2], B:147-153
@@ -873,6 +881,7 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
     MESHENV_STAMP(c, 5);
     if (!ok) {
         d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;  // B:248
+        if (!new_vertex) c.status |= (rule == -1 ? kStRm1Bad : kStRp1Bad);
         return d;
     }
     d.ok = 1;
@@ -979,6 +988,7 @@ __device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d
     }
     MESHENV_STAMP(c, 6);
     c.ring_dirty = true;
+    c.status &= ~(kStRm1Bad | kStRp1Bad);  // new state: forget the memoised rejections
     const bool finished = c.n <= 5;  // B:232-238
     if (finished && c.n == 4) log_quad(c, S, c.id[0], c.id[1], c.id[2], c.id[3]);
     // current_area -= mesh_area (B:200) happens inside: the area needs sin(corner angles), a stage-B job
