@@ -182,6 +182,32 @@ int meshenv_get_elements(MeshEnv *h, int env, int32_t *quads_host, int cap_elems
                          int cap_verts, int32_t *n_elem, int32_t *n_vert);
 
 /*
+ * The same for the last FINISHED episode of the env.  The reference's evaluation callback reads
+ * env.generated_meshes after `done` and before it resets (rl/baselines/CustomizeCallback.py:131-133); under
+ * auto-reset the kernel has already started the next episode by then, so every reset that ends an episode with at
+ * least one element archives that episode's log (double-buffered in HBM, no copy).  *flags: bit 0 = is_complete,
+ * bit 1 = the log overflowed log_capacity; *episodes: number of episodes archived so far (0 = nothing yet, n_elem 0).
+ */
+int meshenv_get_last_episode(MeshEnv *h, int env, int32_t *quads_host, int cap_elems, double *vertex_xy_host,
+                             int cap_verts, int32_t *n_elem, int32_t *n_vert, int32_t *flags, int32_t *episodes);
+
+/*
+ * Per-element quality report, computed on the device for every env at once (one launch).
+ *   which      0 = the running episodes, 1 = the archived (last finished) episodes
+ *   elem_dev   [n_envs][log_capacity][MESHENV_QUALITY_DIM] float64, nullable: per element
+ *                min corner angle (deg), max corner angle (deg), scaled Jacobian, stretch, taper, 'robust',
+ *                area, 'default' -- Mesh.get_quality(type) / compute_area() of general/components.py:863-950, the
+ *                in-repo forms of the five Verdict measures Measurement/quality_verdict.py:133-148 requests;
+ *                rows >= count are left untouched
+ *   stats_dev  [n_envs][MESHENV_QUALITY_DIM][4] float64, nullable: minimum, average, maximum, variance per
+ *                measure over the env's elements (what DumpQualityStats prints, quality_verdict.py:77-90)
+ *   count_dev  [n_envs] int32, nullable: number of elements reported per env
+ * Stream-ordered on the handle's stream.
+ */
+#define MESHENV_QUALITY_DIM 8
+int meshenv_element_quality(MeshEnv *h, int which, double *elem_dev, double *stats_dev, int32_t *count_dev);
+
+/*
  * Work counters since creation (roofline accounting), summed over envs:
  *   out_host[0] env steps executed, [1] valid extractions, [2] sum of ring lengths over all steps,
  *   [3] sum of ring lengths over valid steps.

@@ -139,9 +139,57 @@ def export_fixture():
             env.reset()
 
 
+def reference_element_record(mesh):
+    """The eight per-element measures, each computed by the reference's own Mesh methods."""
+    angles = [mesh.vertices[i].to_find_clockwise_angle(mesh.vertices[(i + 1) % 4], mesh.vertices[i - 1]) for i in range(4)]
+    return [math.degrees(min(angles)), math.degrees(max(angles)), mesh.get_quality(type='s_jacobian'),
+            mesh.get_quality(type='stretch'), mesh.get_quality(type='taper'), mesh.get_quality(type='robust'),
+            mesh.compute_area()[0], mesh.get_quality()]
+
+
+def quality_fixture():
+    """Per-element quality records of every element the reference generates on three action streams, plus the
+    write_2_file JSON (rl/boundary_env.py:648-669) of the first completed boundary0 episode."""
+    import json, tempfile
+    quads, recs, ep = [], [], []
+    w2f = None
+    for dom, kind, seed, T in (("boundary0", "biased", 1, 700), ("boundary16", "biased", 2, 500), ("random1_1", "biased", 1, 300)):
+        pts = H.domain_points(dom)
+        acts = (H.uniform_actions if kind == "uniform" else H.biased_actions)(seed, T)
+        env = H.make_env(pts)
+        env.reset()
+        episode = 0
+        for t in range(T):
+            _, _, done, info = env.step(acts[t])
+            if done or t == T - 1:
+                for m in env.generated_meshes:
+                    quads.append([[float(v.x), float(v.y)] for v in m.vertices])
+                    recs.append(reference_element_record(m))
+                    ep.append(len(ep_keys))
+                ep_keys.append((dom, episode))
+                if w2f is None and dom == "boundary0" and done and info["is_complete"]:
+                    with tempfile.NamedTemporaryFile("r", suffix=".json") as f:
+                        env.write_2_file(f.name)
+                        w2f = {"trace": "boundary0_biased_s1", "step": t, "json": json.load(open(f.name))}
+                episode += 1
+                env.reset()
+    np.savez_compressed(os.path.join(OUT, "quality_quads.npz"), quad_xy=np.asarray(quads, np.float64),
+                        expected=np.asarray(recs, np.float64), episode=np.asarray(ep, np.int32))
+    json.dump(w2f, open(os.path.join(OUT, "write2file_boundary0_biased_s1.json"), "w"))
+    print(f"quality fixture: {len(quads)} elements in {len(ep_keys)} episodes; write_2_file at step {w2f['step']}: "
+          f"{len(w2f['json']['nodes'])} nodes, {len(w2f['json']['elements'])} elements")
+
+
+ep_keys = []
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--quality-only" in sys.argv:
+        quality_fixture()
+        return
     export_fixture()
+    quality_fixture()
     for name, dom, kind, seed, T in TRACES:
         pts = H.domain_points(dom)
         acts = (H.uniform_actions if kind == "uniform" else H.biased_actions)(seed, T)

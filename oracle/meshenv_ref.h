@@ -56,6 +56,10 @@ void meshenv_ref_get_elements(const RefEnv *e, int32_t *quads, double *vertex_xy
 /* batch driver used by tests and by bench.py's cpu_baseline leg: steps n envs once each,
  * auto-resetting finished ones when auto_reset != 0 (obs then holds the reset obs and
  * terminal_obs, if non-NULL, the last obs).  threads > 1 uses OpenMP when compiled with it. */
+/* element quality report (general/components.py:863-933; Measurement/quality_verdict.py:77-90) */
+void meshenv_ref_element_quality(const double *xy /*[4][2]*/, double *out /*[8]*/);
+void meshenv_ref_quality_stats(const double *vals /*[n][8]*/, int n, double *stats /*[8][4]*/);
+
 void meshenv_ref_step_batch(RefEnv **envs, int n, const float *actions, float *obs, double *reward,
                             uint8_t *done, uint8_t *is_complete, float *terminal_obs, int auto_reset,
                             int threads);

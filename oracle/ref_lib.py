@@ -61,8 +61,29 @@ def lib():
     L.meshenv_ref_cw.argtypes = [C.c_double] * 6
     L.meshenv_ref_is_cross.restype = C.c_int
     L.meshenv_ref_is_cross.argtypes = [_f64p, _f64p, _f64p, _f64p]
+    L.meshenv_ref_element_quality.argtypes = [_f64p, _f64p]
+    L.meshenv_ref_quality_stats.argtypes = [_f64p, C.c_int, _f64p]
     _lib = L
     return L
+
+
+def element_quality(quad_xy):
+    """quad_xy [M,4,2] (Mesh.vertices order) -> [M,8] records (see meshenv_ref_element_quality)."""
+    L = lib()
+    q = np.ascontiguousarray(quad_xy, np.float64).reshape(-1, 8)
+    out = np.zeros((q.shape[0], 8), np.float64)
+    for i in range(q.shape[0]):
+        L.meshenv_ref_element_quality(q[i], out[i])
+    return out
+
+
+def quality_stats(vals):
+    """vals [n,8] -> [8,4] = min, mean, max, variance per measure."""
+    L = lib()
+    v = np.ascontiguousarray(vals, np.float64).reshape(-1, 8)
+    st = np.zeros((8, 4), np.float64)
+    L.meshenv_ref_quality_stats(v, int(v.shape[0]), st)
+    return st
 
 
 class RefEnv:

@@ -37,7 +37,7 @@ EXPORTS = [
     "meshenv_step", "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",
     "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times", "meshenv_selftest", "meshenv_set_packed_output",
     "meshenv_actor_create", "meshenv_actor_destroy", "meshenv_actor_set_stream", "meshenv_actor_load",
-    "meshenv_actor_forward",
+    "meshenv_actor_forward", "meshenv_get_last_episode", "meshenv_element_quality",
 ]
 
 
@@ -82,6 +82,8 @@ def load():
     L.meshenv_get_status.argtypes = [vp, vp]
     L.meshenv_get_state.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.meshenv_get_elements.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, i32p, i32p]
+    L.meshenv_get_last_episode.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, i32p, i32p, i32p, i32p]
+    L.meshenv_element_quality.argtypes = [vp, C.c_int, vp, vp, vp]
     L.meshenv_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.meshenv_set_timing.argtypes = [vp, C.c_int]
     L.meshenv_kernel_times.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int32)]
@@ -99,7 +101,8 @@ def load():
         getattr(L, name).restype = C.c_int
     for name in ("meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_reset", "meshenv_step",
                  "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",
-                 "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times"):
+                 "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times", "meshenv_get_last_episode",
+                 "meshenv_element_quality"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -16,6 +16,7 @@
 
 #include "meshenv_actor.h"
 #include "meshenv_kernels.h"
+#include "meshenv_quality.h"
 
 using namespace meshenv;
 
@@ -250,8 +251,10 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
     CREATE_TRY(dev_alloc(h, &S.cnt, (size_t)n_envs));
     CREATE_TRY(dev_alloc(h, &S.obs_cache, (size_t)n_envs * kObsDim));
     if (prm.log_capacity > 0) {
-        CREATE_TRY(dev_alloc(h, &S.log_quads, (size_t)n_envs * prm.log_capacity * 4));
-        CREATE_TRY(dev_alloc(h, &S.log_vxy, (size_t)n_envs * prm.log_capacity));
+        CREATE_TRY(dev_alloc(h, &S.log_quads, (size_t)n_envs * 2 * prm.log_capacity * 4));
+        CREATE_TRY(dev_alloc(h, &S.log_vxy, (size_t)n_envs * 2 * prm.log_capacity));
+        CREATE_TRY(dev_alloc(h, &S.last_ep, (size_t)n_envs));
+        CREATE_HIP(hipMemsetAsync(S.last_ep, 0, sizeof(LastEpisode) * (size_t)n_envs, h->stream));
     }
     S.dom_xy = d_dom_xy;
 #ifdef MESHENV_STAMPS
@@ -428,32 +431,43 @@ int meshenv_get_state(MeshEnv *h, int env, int32_t *ring_ids_host, double *ring_
     return MESHENV_OK;
 }
 
-int meshenv_get_elements(MeshEnv *h, int env, int32_t *quads_host, int cap_elems, double *vertex_xy_host,
-                         int cap_verts, int32_t *n_elem, int32_t *n_vert)
+// shared body of meshenv_get_elements (which = 0) and meshenv_get_last_episode (which = 1)
+static int fetch_elements(MeshEnv *h, const char *fn, int which, int env, int32_t *quads_host, int cap_elems,
+                          double *vertex_xy_host, int cap_verts, int32_t *n_elem, int32_t *n_vert, int32_t *flags,
+                          int32_t *episodes)
 {
     if (!h || !n_elem || !n_vert) return MESHENV_E_ARG;
     if (env < 0 || env >= h->n_envs) {
-        h->err = "meshenv_get_elements: env out of range";
+        h->err = std::string(fn) + ": env out of range";
         return MESHENV_E_RANGE;
     }
     const int cap = h->S.prm.log_cap;
     if (cap <= 0) {
-        h->err = "meshenv_get_elements: handle was created with log_capacity = 0";
+        h->err = std::string(fn) + ": handle was created with log_capacity = 0";
         return MESHENV_E_STATE;
     }
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     EnvScalars s;
     HIP_TRY(h, hipMemcpy(&s, h->S.scal + env, sizeof(s), hipMemcpyDeviceToHost));
+    int half = (s.status >> 4) & 1, ne = s.n_elem, nnew = s.n_new;
+    if (which) {
+        LastEpisode le;
+        HIP_TRY(h, hipMemcpy(&le, h->S.last_ep + env, sizeof(le), hipMemcpyDeviceToHost));
+        half ^= 1; ne = le.n_elem; nnew = le.n_new;
+        if (flags) *flags = le.flags;
+        if (episodes) *episodes = le.episodes;
+    }
     const int d = s.dom;
     const int n0 = h->dom_off_host[d + 1] - h->dom_off_host[d];
-    int ne = s.n_elem < cap ? s.n_elem : cap;
-    int nnew = s.n_new < cap ? s.n_new : cap;
+    ne = ne < cap ? ne : cap;
+    nnew = nnew < cap ? nnew : cap;
     if (ne > cap_elems) ne = cap_elems;
     int nv = n0 + nnew;
     if (nv > cap_verts) nv = cap_verts;
+    const size_t base = ((size_t)env * 2 + half) * cap;
     if (quads_host && ne > 0) {
-        HIP_TRY(h, hipMemcpy(quads_host, h->S.log_quads + (size_t)env * cap * 4, sizeof(int32_t) * 4 * (size_t)ne, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(quads_host, h->S.log_quads + base * 4, sizeof(int32_t) * 4 * (size_t)ne, hipMemcpyDeviceToHost));
         for (int i = 0; i < 4 * ne; i++)
             if (quads_host[i] & kNewBit) quads_host[i] = n0 + (quads_host[i] & ~kNewBit);
     }
@@ -461,10 +475,38 @@ int meshenv_get_elements(MeshEnv *h, int env, int32_t *quads_host, int cap_elems
         const int first = nv < n0 ? nv : n0;
         HIP_TRY(h, hipMemcpy(vertex_xy_host, h->S.dom_xy + h->dom_off_host[d], sizeof(double2) * (size_t)first, hipMemcpyDeviceToHost));
         if (nv > n0)
-            HIP_TRY(h, hipMemcpy(vertex_xy_host + 2 * (size_t)n0, h->S.log_vxy + (size_t)env * cap, sizeof(double2) * (size_t)(nv - n0), hipMemcpyDeviceToHost));
+            HIP_TRY(h, hipMemcpy(vertex_xy_host + 2 * (size_t)n0, h->S.log_vxy + base, sizeof(double2) * (size_t)(nv - n0), hipMemcpyDeviceToHost));
     }
     *n_elem = ne;
     *n_vert = nv;
+    return MESHENV_OK;
+}
+
+int meshenv_get_elements(MeshEnv *h, int env, int32_t *quads_host, int cap_elems, double *vertex_xy_host,
+                         int cap_verts, int32_t *n_elem, int32_t *n_vert)
+{
+    return fetch_elements(h, "meshenv_get_elements", 0, env, quads_host, cap_elems, vertex_xy_host, cap_verts, n_elem,
+                          n_vert, nullptr, nullptr);
+}
+
+int meshenv_get_last_episode(MeshEnv *h, int env, int32_t *quads_host, int cap_elems, double *vertex_xy_host,
+                             int cap_verts, int32_t *n_elem, int32_t *n_vert, int32_t *flags, int32_t *episodes)
+{
+    return fetch_elements(h, "meshenv_get_last_episode", 1, env, quads_host, cap_elems, vertex_xy_host, cap_verts,
+                          n_elem, n_vert, flags, episodes);
+}
+
+int meshenv_element_quality(MeshEnv *h, int which, double *elem_dev, double *stats_dev, int32_t *count_dev)
+{
+    if (!h || (which != 0 && which != 1)) return MESHENV_E_ARG;
+    if (h->S.prm.log_cap <= 0) {
+        h->err = "meshenv_element_quality: handle was created with log_capacity = 0";
+        return MESHENV_E_STATE;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_element_quality, dim3(h->n_envs), dim3(64), 0, h->stream, h->S, which, elem_dev, stats_dev,
+                       count_dev);
+    HIP_TRY(h, hipGetLastError());
     return MESHENV_OK;
 }
 

@@ -27,7 +27,7 @@ constexpr int kStLogOverflow = 2;
 // boundary intersection test are pure functions of the state, so a repeated attempt needs no geometry at all);
 // cleared whenever the state changes (extraction, reset)
 constexpr int kStRm1Bad = 4, kStRp1Bad = 8;
-constexpr int kNewBit = 0x40000000;  // ring_id of the k-th vertex created this episode = kNewBit | k
+constexpr int kStLogHalf = 16;  // which half of the element / vertex log the running episode writes
 
 // scratch area appended to the LDS ring arrays
 #ifdef MESHENV_STAMPS
@@ -704,6 +704,19 @@ __device__ __forceinline__ double quad_max_dist(int lane, P2 ref, P2 a, P2 b, P2
 // reset(): copy the domain's precomputed reset state (B:67-84 computes only per-domain constants)
 __device__ __forceinline__ void reset_from_domain(Ctx &c, const DevState &S)
 {
+    // archive the finished episode's log: flip the log half (c holds the pre-reset n, n_elem, n_new, status)
+    int half = c.status & kStLogHalf;
+    if (S.prm.log_cap > 0 && c.n_elem > 0) {
+        if (c.lane == 0) {
+            LastEpisode le;
+            le.n_elem = c.n_elem;
+            le.n_new = c.n_new;
+            le.flags = (c.n <= 5 ? 1 : 0) | (c.status & kStLogOverflow);
+            le.episodes = S.last_ep[c.env].episodes + 1;
+            S.last_ep[c.env] = le;
+        }
+        half ^= kStLogHalf;
+    }
     const DomConst dc = S.dom[c.dom];
     const int doff = uniform_i32(dc.off), n0 = uniform_i32(dc.n0);
     wave_sync();
@@ -720,7 +733,7 @@ __device__ __forceinline__ void reset_from_domain(Ctx &c, const DevState &S)
     c.st = uniform_f64(dc.st);
     c.area = uniform_f64(dc.orig_area);
     c.n_elem = 0; c.failed = 0; c.n_new = 0; c.counter = 0;
-    c.status = c.ref < 0 ? kStNoReference : 0;
+    c.status = (c.ref < 0 ? kStNoReference : 0) | half;
     c.obs = c.lane < kObsDim ? S.dom_obs[(size_t)c.dom * kObsDim + c.lane] : 0.0f;
     c.ring_dirty = true;
     wave_sync();
@@ -731,7 +744,7 @@ __device__ __forceinline__ void log_quad(Ctx &c, const DevState &S, int g0, int 
     const int cap = S.prm.log_cap;
     if (c.n_elem < cap) {
         if (c.lane == 0) {
-            int32_t *dst = S.log_quads + ((size_t)c.env * cap + c.n_elem) * 4;
+            int32_t *dst = S.log_quads + (((size_t)c.env * 2 + ((c.status >> 4) & 1)) * cap + c.n_elem) * 4;
             dst[0] = g0; dst[1] = g1; dst[2] = g2; dst[3] = g3;
         }
     } else if (cap > 0) {
@@ -948,7 +961,7 @@ __device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d
             c.id[index] = kNewBit | c.n_new;
             c.stamp[index] = kNotCand;
             const int cap = prm.log_cap;
-            if (c.n_new < cap) S.log_vxy[(size_t)c.env * cap + c.n_new] = make_double2(d.new_point.x, d.new_point.y);
+            if (c.n_new < cap) S.log_vxy[((size_t)c.env * 2 + ((c.status >> 4) & 1)) * cap + c.n_new] = make_double2(d.new_point.x, d.new_point.y);
         }
         if (prm.log_cap > 0 && c.n_new >= prm.log_cap) c.status |= kStLogOverflow;
         c.n_new += 1;
@@ -1108,6 +1121,14 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
     c.env = env;
     c.base = (size_t)env * S.cap;
     c.dom = uniform_i32(S.scal[env].dom);
+    if (first) {
+        c.n = 0; c.n_elem = 0; c.n_new = 0; c.status = 0;
+    } else {
+        c.n = uniform_i32(S.scal[env].n);
+        c.n_elem = uniform_i32(S.scal[env].n_elem);
+        c.n_new = uniform_i32(S.scal[env].n_new);
+        c.status = uniform_i32(S.scal[env].status);
+    }
     reset_from_domain(c, S);
     if (first && c.lane == 0) {
         EnvCounters z;

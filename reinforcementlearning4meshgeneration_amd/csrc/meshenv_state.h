@@ -54,6 +54,14 @@ struct Params {
     int fail_limit, log_cap;
 };
 
+constexpr int kNewBit = 0x40000000;  // ring_id of the k-th vertex created this episode = kNewBit | k
+
+struct LastEpisode {
+    int32_t n_elem, n_new;    // elements / created vertices of the archived episode
+    int32_t flags;            // bit 0: is_complete (ring <= 5), bit 1: log overflow
+    int32_t episodes;         // episodes archived so far
+};
+
 struct DevState {
     // ---- domain table
     int n_domains;
@@ -74,8 +82,12 @@ struct DevState {
     float *obs_cache;         // [E][18] observation of the current state
     float *msg;               // optional [E][21] packed (obs | reward | done | complete) float32 output, NULL = off
     // ---- logs (generated_meshes / boundary.vertices), optional
-    int32_t *log_quads;       // [E][log_cap][4]
-    double2 *log_vxy;         // [E][log_cap]
+    // Two halves per env: the running episode writes half (status >> 4) & 1; a reset that ends an episode with
+    // elements flips the bit, so the finished mesh (what the reference's eval callback reads from
+    // env.generated_meshes before it resets, CustomizeCallback.py:131-133) stays readable under auto-reset.
+    int32_t *log_quads;       // [E][2][log_cap][4]
+    double2 *log_vxy;         // [E][2][log_cap]
+    LastEpisode *last_ep;     // [E] extent of the archived half
 #ifdef MESHENV_STAMPS
     unsigned long long *dbg;  // [E][16] diagnostic build: in-kernel timeline stamps
 #endif

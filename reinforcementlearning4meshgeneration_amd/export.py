@@ -46,3 +46,35 @@ def inp_text(quads: np.ndarray, vertex_xy: np.ndarray, domain_points: Sequence) 
 def write_inp(filename, quads, vertex_xy, domain_points) -> None:
     with open(filename, "w") as fw:
         fw.write(inp_text(quads, vertex_xy, domain_points))
+
+
+def mesh_graph(quads: np.ndarray, vertex_xy: np.ndarray, domain_points: Sequence) -> dict:
+    """The dictionary BoudaryEnv.write_2_file dumps (rl/boundary_env.py:648-669): every vertex with its coordinates
+    and the ids it shares a segment with, in the order the reference created those segments -- the polygon's own edges
+    first (connect_vertices, general/mesh.py:1926-1930), then, element by element, the quad edges that did not exist
+    yet (Mesh.connect_vertices, general/components.py:832-837) -- and the elements as vertex ids."""
+    n0 = len(domain_points)
+    nv = len(vertex_xy)
+    connected = [[] for _ in range(nv)]
+    for i in range(n0):
+        a, b = (i - 1) % n0, i
+        connected[a].append(b)
+        connected[b].append(a)
+    for q in quads:
+        for i in range(4):
+            a, b = int(q[i]), int(q[i - 1])
+            if b not in connected[a]:
+                connected[a].append(b)
+                connected[b].append(a)
+    nodes = {}
+    for v in range(nv):
+        xy = domain_points[v] if v < n0 else (float(vertex_xy[v, 0]), float(vertex_xy[v, 1]))
+        nodes[v] = {"coordinates": [xy[0], xy[1]], "connected": connected[v]}
+    elements = {k: [int(v) for v in q] for k, q in enumerate(quads)}
+    return {"nodes": nodes, "elements": elements}
+
+
+def write_2_file(filename, quads, vertex_xy, domain_points) -> None:
+    import json
+    with open(filename, "w") as fw:
+        json.dump(mesh_graph(quads, vertex_xy, domain_points), fw)

@@ -15,7 +15,8 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    """Recorded reference traces (quality_*.npz holds element records, not a trace)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("quality_"))
 
 
 @pytest.fixture(scope="session")

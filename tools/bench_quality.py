@@ -1,0 +1,48 @@
+"""Dev tool: time the device-side quality report (k_element_quality) and price it against the HBM roofline.
+
+Algorithmic bytes per launch = per element 16 B (quad ids) + 64 B (record) ; per vertex referenced 16 B (each
+vertex is shared by ~4 elements, counted once); per env 64 B scalars + 16 B archive extent + 256 B statistics + 4 B
+count.  usage: python tools/bench_quality.py [n_envs] [steps]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reinforcementlearning4meshgeneration_amd import MeshVecEnv, boundary
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+cap = 64
+env = MeshVecEnv([boundary(0)], n_envs=n, auto_reset=True, log_capacity=cap)
+env.reset()
+g = torch.Generator(device="cuda"); g.manual_seed(3)
+lo = torch.tensor([-1, 0.2, 0.3], device="cuda"); hi = torch.tensor([1, 1.0, 1.2], device="cuda")
+for t in range(T):
+    a = lo + (hi - lo) * torch.rand((n, 3), device="cuda", generator=g)
+    env.step(a)
+rec = torch.zeros((n, cap, 8), dtype=torch.float64, device="cuda")
+stats = torch.empty((n, 8, 4), dtype=torch.float64, device="cuda")
+cnt = torch.empty(n, dtype=torch.int32, device="cuda")
+L, h = env._L, env._handle
+def launch(with_rec=True):
+    rc = L.meshenv_element_quality(h, 1, rec.data_ptr() if with_rec else None, stats.data_ptr(), cnt.data_ptr())
+    assert rc == 0
+for mode in (True, False):
+    for _ in range(3): launch(mode)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    K = 20
+    e0.record()
+    for _ in range(K): launch(mode)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / K
+    c = cnt.cpu().numpy().astype(np.int64)
+    ne = int(c.sum())
+    # vertices referenced: n0 + created ones ~ one per rule-0 element; bound by reading the archive extents
+    nv = 0
+    for k in np.random.default_rng(0).choice(n, 64, replace=False):
+        le = env.get_last_episode(int(k)); nv += len(np.unique(le["quads"]))
+    nv = nv / 64 * n
+    by = ne * (16 + (64 if mode else 0)) + nv * 16 + n * (64 + 16 + 256 + 4)
+    print(f"records={'on' if mode else 'off'}: {ms*1e3:.1f} us/launch, {ne} elements ({ne/n:.1f}/env), "
+          f"{ne/ms/1e6:.2f} G elements/s, algorithmic {by/1e6:.1f} MB -> {by/ms/1e6:.0f} GB/s = {by/ms/1e6/8000*100:.1f}% of 8 TB/s")
+rep = env.quality_report("last")
+print({k: (round(v["average"], 4), round(v["std"], 4)) for k, v in rep.items() if isinstance(v, dict)})
