@@ -127,7 +127,11 @@ k_element_quality(DevState S, int which, double *__restrict__ elem_out, double *
         P2 m[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const double2 v = (gid[k] & kNewBit) ? vnew[gid[k] & ~kNewBit] : S.dom_xy[doff + gid[k]];
+            // a created vertex past log_capacity was never stored (MESHENV_ST_LOG_OVERFLOW): NaN record, no read
+            const int kn = gid[k] & ~kNewBit;
+            const bool created = (gid[k] & kNewBit) != 0;
+            const double kNaN = __builtin_nan("");
+            const double2 v = created ? (kn < cap ? vnew[kn] : make_double2(kNaN, kNaN)) : S.dom_xy[doff + gid[k]];
             m[k] = mkp(v.x, v.y);
         }
         double q[kQualityDim];
