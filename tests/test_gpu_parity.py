@@ -204,3 +204,29 @@ def test_group_kernel_on_long_ragged_rings(torch_cuda, monkeypatch):
     st = _run_lockstep(torch_cuda, doms, env_domain, a.astype(np.float32), check_every=16, sample=96)
     print("group/ragged:", st)
     assert st["valid"] > 0.1 * n * T
+
+
+def test_non_finite_and_extreme_actions(torch_cuda):
+    """NaN / inf / huge / signed-zero action components: the reference neither clips nor raises (a NaN rule type falls
+    through to rule 0, a non-finite point fails the point-in-polygon test); device and oracle must agree."""
+    from reinforcementlearning4meshgeneration_amd.domains import boundary, random_domain
+    odd = np.array([[np.nan, 0.5, 0.5], [0, np.nan, 0.5], [0, 0.5, np.nan], [0, np.inf, 0.5], [0, 0.5, -np.inf],
+                    [np.inf, 0.3, 0.3], [-np.inf, 0.3, 0.3], [0, 1e30, 1e30], [0, -0.0, -0.0], [0, 0.0, 0.0],
+                    [1, np.nan, np.nan], [-1, np.inf, np.nan], [0, 1e-30, 1e-30], [0, 3e38, -3e38],
+                    [np.nan, np.nan, np.nan], [0.5, 0.0, 1e-4], [-0.5, 1e-4, 0.0]], np.float32)
+    doms = [boundary(0), random_domain(3)]
+    n, T = 128, 160
+    rng = np.random.default_rng(17)
+    a = rng.uniform([-1, -1.5, 0], [1, 1.5, 1.5], size=(T, n, 3))
+    b = np.stack([rng.uniform(-1, 1, (T, n)), rng.uniform(0.2, 1.0, (T, n)), rng.uniform(0.3, 1.2, (T, n))], axis=2)
+    pick = rng.random((T, n)) < 0.5
+    a[pick] = b[pick]
+    a = a.astype(np.float32)
+    use_odd = rng.random((T, n)) < 0.3
+    a[use_odd] = odd[rng.integers(0, len(odd), int(use_odd.sum()))]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        st = _run_lockstep(torch_cuda, doms, (np.arange(n) % 2).astype(np.int32), a, check_every=40, sample=128)
+    print("odd actions:", st)
+    assert st["valid"] > 0
