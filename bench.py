@@ -46,7 +46,7 @@ def pmc_traffic(n_envs):
             if f.endswith("_summary.json"):
                 try:
                     d = json.load(open(os.path.join(pdir, f)))
-                    if d.get("bench_line_under_rocprof", {}).get("config", {}).get("n_envs_per_gpu") == n_envs:
+                    if d.get("n_envs_per_gpu", d.get("bench_line_under_rocprof", {}).get("config", {}).get("n_envs_per_gpu")) == n_envs:
                         best = (d["hbm_traffic_bytes_per_launch"]["gfx950_corrected_(2*FETCH+WRITE)*1024"], "profiles/" + f)
                 except Exception:
                     pass

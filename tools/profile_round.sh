@@ -4,6 +4,7 @@ tag=${1:-r01}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/prof_$tag
+rm -rf $out
 mkdir -p $out
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/trace.log
