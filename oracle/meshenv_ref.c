@@ -612,7 +612,7 @@ int meshenv_ref_reset(RefEnv *e, float *obs)
 int meshenv_ref_step(RefEnv *e, const float *action, float *obs, double *reward_out, uint8_t *done_out,
                      uint8_t *complete_out)
 {
-    int done = 0, failed = 1;
+    int done = 0, failed = 1, no_reference = 0;
     double reward = 0;
     const float rule_type = action[0];
 
@@ -637,8 +637,11 @@ int meshenv_ref_step(RefEnv *e, const float *action, float *obs, double *reward_
     }
 
     if (index < 0) {
-        /* the reference would have crashed one call earlier (obs None); keep the env inert */
+        /* the reference's find_next_state returned None and this step() would raise; the documented replacement
+         * behaviour (include/meshenv.h, MESHENV_ST_NO_REFERENCE) is: reward -1, episode ends as truncated */
         reward = -1;
+        done = 1;
+        no_reference = 1;
     } else if (e->n <= 5) {
         reward = 10; /* B:158-160 */
         done = 1;
@@ -728,7 +731,7 @@ int meshenv_ref_step(RefEnv *e, const float *action, float *obs, double *reward_
             }
         }
     }
-    int is_complete = 1;
+    int is_complete = no_reference ? 0 : 1;
     int none = find_next_state(e, obs);
     if (!failed) {
         e->failed = 0;

@@ -6,7 +6,7 @@ ZhuoQiuMcgill/ReinforcementLearning4MeshGeneration as hand-written HIP kernels b
 from .domains import boundary, domain_constants, generate_polygon, random_domain, read_polygon  # noqa: F401
 
 __all__ = ["MeshVecEnv", "BoudaryEnv", "boundary", "read_polygon", "domain_constants", "generate_polygon",
-           "random_domain"]
+           "random_domain", "MeshEnvError", "FusedActor"]
 
 
 def __getattr__(name):  # torch / the HIP library are only needed once an environment is built
@@ -16,4 +16,10 @@ def __getattr__(name):  # torch / the HIP library are only needed once an enviro
     if name == "BoudaryEnv":
         from .boundary_env import BoudaryEnv
         return BoudaryEnv
+    if name == "MeshEnvError":
+        from ._capi import MeshEnvError
+        return MeshEnvError
+    if name == "FusedActor":
+        from .actor import FusedActor
+        return FusedActor
     raise AttributeError(name)

@@ -148,7 +148,7 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
             return fail_arg(nullptr, "meshenv_create: env_domain entry out of range");
     const int cap = (max_ring + 15) / 16 * 16;
     const size_t lds = lds_bytes_for(cap);
-    if (lds > 160 * 1024) return fail_arg(nullptr, "meshenv_create: ring too long for one CU's LDS (max ~4800 vertices)");
+    if (lds > 160 * 1024) return fail_arg(nullptr, "meshenv_create: ring too long for one CU's LDS (160 KB: about 3600 vertices)");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
