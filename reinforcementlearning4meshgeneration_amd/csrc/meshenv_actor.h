@@ -7,9 +7,13 @@
 // step itself; this kernel is the whole forward in one launch so that observations and actions never leave the GPU
 // and the rollout loop stays at two launches per vector step.
 //
-// fp32 FMA (no MFMA: 4096 x 128 x 128 is 0.3 GFLOP per step, launch-latency territory), weights transposed to
-// [in][out] at upload so that lane j reads W[k][j] coalesced, activations transposed in LDS ([k][env]) so that one
-// ds_read_b128 feeds four environments.  32 environments per 256-thread workgroup: thread t computes 4 neurons x 4 envs.
+// GEMM-shaped, so it runs on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate -- bit-for-bit a
+// k-ordered fmaf chain, no reduced precision).  16 environments per 256-thread workgroup (4096 envs -> 256 workgroups,
+// one per CU); wave w owns neurons [32w, 32w + 32) as two 16x16 accumulator tiles (two independent chains cover the
+// 40-cycle dependent MFMA latency).  The B operand (weights) of a whole layer lives in registers: 64 floats per lane,
+// packed on the host in exactly the per-lane order so that a wave loads them with sixteen coalesced 1 KB requests,
+// issued one layer ahead of their use.  The A operand (activations) goes through LDS in a k-permuted layout
+// ([env][k & 3][k >> 2], row stride 132 floats) so that one conflict-free ds_read_b128 feeds four MFMA k-steps.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -17,40 +21,65 @@
 
 namespace meshenv {
 
-constexpr int kActIn = 18, kActHid = 128, kActOut = 3, kActEnvs = 32;
+constexpr int kActIn = 18, kActHid = 128, kActOut = 3;
+constexpr int kActEnvs = 16;    // environments per workgroup = MFMA M
+constexpr int kActInPad = 32;   // layer-1 K padded to a multiple of 16
+constexpr int kActStride = 132; // LDS row stride in floats: 132 mod 64 = 4 -> 16 lanes x 16 B hit 64 distinct banks
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Packed weight of a layer with K inputs: [wave 4][tile 2][K/16][lane 64][4]; element j of lane l in group g is
+// W[k = 4 * (4 g + j) + (l >> 4)][n = 32 wave + 16 tile + (l & 15)]  (meshenv_actor_load builds it).
 struct ActorWeights {
-    const float *w1t, *b1;   // [18][128], [128]
-    const float *w2t, *b2;   // [128][128], [128]
-    const float *w3t, *b3;   // [128][128], [128]
-    const float *wht, *bh;   // heads: [128][8] (mu0..2, log_std0..2, 0, 0), [8]
+    const float *w1p, *b1;  // K = 32 (18 padded), [128]
+    const float *w2p, *b2;  // K = 128
+    const float *w3p, *b3;  // K = 128
+    const float *whp, *bh;  // heads: one 16-wide tile [8][64][4] (n = mu0..2, log_std0..2, zeros), [16]
     float low[3], high[3];
 };
 
-// one hidden layer: y[j][e] = relu(b[j] + sum_k W[k][j] * x[k][e]); thread t: neurons 4*(t&31).., envs 4*(t>>5)..
-template <int K>
-__device__ __forceinline__ void actor_layer(const float *__restrict__ wt, const float *__restrict__ b,
-                                            const float *xT /*[K][32]*/, float *yT /*[128][32]*/)
+template <int G>  // G = K / 16 float4 groups per tile
+struct LayerRegs {
+    f32x4 w[2][G];
+};
+
+template <int G>
+__device__ __forceinline__ void load_layer(LayerRegs<G> &r, const float *__restrict__ wp, int wave, int lane)
 {
-    const int t = threadIdx.x, jg = t & 31, eg = t >> 5;
-    float acc[4][4];
-    const float4 bv = *reinterpret_cast<const float4 *>(b + 4 * jg);
 #pragma unroll
-    for (int e = 0; e < 4; e++) { acc[0][e] = bv.x; acc[1][e] = bv.y; acc[2][e] = bv.z; acc[3][e] = bv.w; }
-#pragma unroll 4
-    for (int k = 0; k < K; k++) {
-        const float4 w = *reinterpret_cast<const float4 *>(wt + (size_t)k * kActHid + 4 * jg);
-        const float4 x = *reinterpret_cast<const float4 *>(xT + k * kActEnvs + 4 * eg);
-        acc[0][0] = fmaf(w.x, x.x, acc[0][0]); acc[0][1] = fmaf(w.x, x.y, acc[0][1]); acc[0][2] = fmaf(w.x, x.z, acc[0][2]); acc[0][3] = fmaf(w.x, x.w, acc[0][3]);
-        acc[1][0] = fmaf(w.y, x.x, acc[1][0]); acc[1][1] = fmaf(w.y, x.y, acc[1][1]); acc[1][2] = fmaf(w.y, x.z, acc[1][2]); acc[1][3] = fmaf(w.y, x.w, acc[1][3]);
-        acc[2][0] = fmaf(w.z, x.x, acc[2][0]); acc[2][1] = fmaf(w.z, x.y, acc[2][1]); acc[2][2] = fmaf(w.z, x.z, acc[2][2]); acc[2][3] = fmaf(w.z, x.w, acc[2][3]);
-        acc[3][0] = fmaf(w.w, x.x, acc[3][0]); acc[3][1] = fmaf(w.w, x.y, acc[3][1]); acc[3][2] = fmaf(w.w, x.z, acc[3][2]); acc[3][3] = fmaf(w.w, x.w, acc[3][3]);
+    for (int tile = 0; tile < 2; tile++)
+#pragma unroll
+        for (int g = 0; g < G; g++)
+            r.w[tile][g] = *reinterpret_cast<const f32x4 *>(wp + ((((size_t)wave * 2 + tile) * G + g) * 64 + lane) * 4);
+}
+
+// y = relu(W x + b) for the wave's 32 neurons; x: LDS [16][kActStride] in the permuted layout of a K-input layer
+// (position (k & 3) * (K / 4) + (k >> 2)); y: the 128-input layout of the next layer
+template <int G>
+__device__ __forceinline__ void actor_layer(const LayerRegs<G> &r, const float *__restrict__ bias, const float *x, float *y,
+                                            int wave, int lane)
+{
+    const int e = lane & 15, q = lane >> 4;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const float *xr = x + e * kActStride + q * (4 * G);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], r.w[0][g][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], r.w[1][g][j], acc1, 0, 0, 0);
+        }
     }
+    // D[row = 4 (lane >> 4) + reg][col = lane & 15]
+    const int n0 = 32 * wave + e, n1 = n0 + 16;
+    const float b0 = bias[n0], b1 = bias[n1];
+    const int p0 = (n0 & 3) * 32 + (n0 >> 2), p1 = (n1 & 3) * 32 + (n1 >> 2);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        float4 o;
-        o.x = fmaxf(acc[j][0], 0.0f); o.y = fmaxf(acc[j][1], 0.0f); o.z = fmaxf(acc[j][2], 0.0f); o.w = fmaxf(acc[j][3], 0.0f);
-        *reinterpret_cast<float4 *>(yT + (4 * jg + j) * kActEnvs + 4 * eg) = o;
+    for (int reg = 0; reg < 4; reg++) {
+        float *row = y + (4 * q + reg) * kActStride;
+        row[p0] = fmaxf(acc0[reg] + b0, 0.0f);
+        row[p1] = fmaxf(acc1[reg] + b1, 0.0f);
     }
 }
 
@@ -58,42 +87,64 @@ __global__ void __launch_bounds__(256)
 k_actor_forward(ActorWeights W, int n, const float *__restrict__ obs, const float *__restrict__ noise,
                 float *__restrict__ actions)
 {
-    __shared__ __attribute__((aligned(16))) float bufA[kActHid * kActEnvs];
-    __shared__ __attribute__((aligned(16))) float bufB[kActHid * kActEnvs];
-    const int t = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float bufA[kActEnvs * kActStride];
+    __shared__ __attribute__((aligned(16))) float bufB[kActEnvs * kActStride];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int env0 = blockIdx.x * kActEnvs;
-    // observations -> bufB as [k][env] (zero for envs past n)
-    for (int i = t; i < kActIn * kActEnvs; i += 256) {
-        const int e = i / kActIn, k = i - e * kActIn;
-        bufB[k * kActEnvs + e] = (env0 + e < n) ? obs[(size_t)(env0 + e) * kActIn + k] : 0.0f;
+
+    LayerRegs<2> r1;
+    LayerRegs<8> r2, r3;
+    load_layer<2>(r1, W.w1p, wave, lane);
+    load_layer<8>(r2, W.w2p, wave, lane);
+    // observations -> bufA in the K = 32 layout (zero for k >= 18 and for envs past n)
+    for (int i = t; i < kActEnvs * kActInPad; i += 256) {
+        const int e = i >> 5, k = i & 31;
+        const float v = (k < kActIn && env0 + e < n) ? obs[(size_t)(env0 + e) * kActIn + k] : 0.0f;
+        bufA[e * kActStride + (k & 3) * (kActInPad / 4) + (k >> 2)] = v;
     }
     __syncthreads();
-    actor_layer<kActIn>(W.w1t, W.b1, bufB, bufA);
+    actor_layer<2>(r1, W.b1, bufA, bufB, wave, lane);
+    load_layer<8>(r3, W.w3p, wave, lane);
     __syncthreads();
-    actor_layer<kActHid>(W.w2t, W.b2, bufA, bufB);
-    __syncthreads();
-    actor_layer<kActHid>(W.w3t, W.b3, bufB, bufA);
-    __syncthreads();
-    // heads: thread t < 192 -> (env e = t / 6, output o = t % 6): mu0..2, log_std0..2
-    float v = 0.0f;
-    const int e = t / 6, o = t - 6 * e;
-    if (t < 6 * kActEnvs) {
-        v = W.bh[o];
-        for (int k = 0; k < kActHid; k++) v = fmaf(W.wht[k * 8 + o], bufA[k * kActEnvs + e], v);
+    actor_layer<8>(r2, W.b2, bufB, bufA, wave, lane);
+    f32x4 wh[8];
+    if (wave == 0) {
+#pragma unroll
+        for (int g = 0; g < 8; g++) wh[g] = *reinterpret_cast<const f32x4 *>(W.whp + ((size_t)g * 64 + lane) * 4);
     }
     __syncthreads();
-    if (t < 6 * kActEnvs) bufB[e * 8 + o] = v;
+    actor_layer<8>(r3, W.b3, bufA, bufB, wave, lane);
     __syncthreads();
-    if (t < 3 * kActEnvs) {
-        const int ee = t / 3, a = t - 3 * ee;
-        if (env0 + ee < n) {
-            float mu = bufB[ee * 8 + a];
+    if (wave != 0) return;
+    // heads on wave 0: one 16-wide tile, two accumulators over even / odd k-groups
+    const int e = lane & 15, q = lane >> 4;
+    f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
+    const float *xr = bufB + e * kActStride + q * 32;
+#pragma unroll
+    for (int g = 0; g < 8; g += 2) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(xr + 4 * g);
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(xr + 4 * g + 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], wh[g][j], h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], wh[g + 1][j], h1, 0, 0, 0);
+        }
+    }
+    const float bh = W.bh[e];
+    // lane (col e, rows 4 q + reg): col a < 3 is mu_a, col 3 + a its log_std
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const float v = h0[reg] + h1[reg] + bh;
+        const float ls_raw = __shfl(v, lane + 3, 64);
+        const int env = env0 + 4 * q + reg;
+        if (e < kActOut && env < n) {
+            float mu = v;
             if (noise) {
-                const float ls = fminf(fmaxf(bufB[ee * 8 + 3 + a], -20.0f), 2.0f);
-                mu += expf(ls) * noise[(size_t)(env0 + ee) * 3 + a];
+                const float ls = fminf(fmaxf(ls_raw, -20.0f), 2.0f);
+                mu += expf(ls) * noise[(size_t)env * 3 + e];
             }
             const float sq = tanhf(mu);
-            actions[(size_t)(env0 + ee) * 3 + a] = W.low[a] + 0.5f * (sq + 1.0f) * (W.high[a] - W.low[a]);
+            actions[(size_t)env * 3 + e] = W.low[e] + 0.5f * (sq + 1.0f) * (W.high[e] - W.low[e]);
         }
     }
 }

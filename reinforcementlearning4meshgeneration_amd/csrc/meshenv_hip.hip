@@ -621,6 +621,7 @@ struct MeshActor {
     int device = 0;
     hipStream_t stream = nullptr;
     float *buf = nullptr;  // all weights, one allocation
+    size_t nfloat = 0;
     ActorWeights W{};
     bool loaded = false;
     std::string err;
@@ -638,8 +639,8 @@ int meshenv_actor_create(int device, void *stream, MeshActor **out)
     MeshActor *a = new MeshActor();
     a->device = device;
     a->stream = (hipStream_t)stream;
-    const size_t nfloat = (size_t)kActIn * kActHid + kActHid + 2 * ((size_t)kActHid * kActHid + kActHid) + (size_t)kActHid * 8 + 8;
-    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&a->buf, nfloat * sizeof(float)) != hipSuccess) {
+    a->nfloat = (size_t)kActInPad * kActHid + kActHid + 2 * ((size_t)kActHid * kActHid + kActHid) + (size_t)kActHid * 16 + 16;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&a->buf, a->nfloat * sizeof(float)) != hipSuccess) {
         g_create_error = "meshenv_actor_create: hipMalloc failed";
         delete a;
         return MESHENV_E_HIP;
@@ -672,11 +673,20 @@ int meshenv_actor_load(MeshActor *a, const float *w1, const float *b1, const flo
     if (!a || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w_mu || !b_mu || !w_log_std || !b_log_std || !low || !high)
         return MESHENV_E_ARG;
     std::vector<float> h;
-    auto transposed = [&](const float *w, int out, int in, int out_pad) {  // [out][in] -> [in][out_pad]
+    // torch [out][in] -> the per-lane MFMA B-operand order of meshenv_actor.h: [wave][tile][K/16][lane][4]
+    auto packed = [&](const float *w, int out, int in, int k_pad, int waves) {
         const size_t off = h.size();
-        h.resize(off + (size_t)in * out_pad, 0.0f);
-        for (int o = 0; o < out; o++)
-            for (int k = 0; k < in; k++) h[off + (size_t)k * out_pad + o] = w[(size_t)o * in + k];
+        const int groups = k_pad / 16;
+        h.resize(off + (size_t)waves * 2 * groups * 64 * 4, 0.0f);
+        for (int wv = 0; wv < waves; wv++)
+            for (int tile = 0; tile < 2; tile++)
+                for (int g = 0; g < groups; g++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 4; j++) {
+                            const int k = 4 * (4 * g + j) + (lane >> 4), n = 32 * wv + 16 * tile + (lane & 15);
+                            if (k < in && n < out)
+                                h[off + ((((size_t)wv * 2 + tile) * groups + g) * 64 + lane) * 4 + j] = w[(size_t)n * in + k];
+                        }
         return off;
     };
     auto plain = [&](const float *b, int n, int pad) {
@@ -685,28 +695,38 @@ int meshenv_actor_load(MeshActor *a, const float *w1, const float *b1, const flo
         for (int i = 0; i < n; i++) h[off + i] = b[i];
         return off;
     };
-    const size_t o_w1 = transposed(w1, kActHid, kActIn, kActHid), o_b1 = plain(b1, kActHid, kActHid);
-    const size_t o_w2 = transposed(w2, kActHid, kActHid, kActHid), o_b2 = plain(b2, kActHid, kActHid);
-    const size_t o_w3 = transposed(w3, kActHid, kActHid, kActHid), o_b3 = plain(b3, kActHid, kActHid);
-    const size_t o_wh = h.size();
-    h.resize(o_wh + (size_t)kActHid * 8, 0.0f);
-    for (int k = 0; k < kActHid; k++)
-        for (int o = 0; o < 3; o++) {
-            h[o_wh + (size_t)k * 8 + o] = w_mu[(size_t)o * kActHid + k];
-            h[o_wh + (size_t)k * 8 + 3 + o] = w_log_std[(size_t)o * kActHid + k];
+    const size_t o_w1 = packed(w1, kActHid, kActIn, kActInPad, 4), o_b1 = plain(b1, kActHid, kActHid);
+    const size_t o_w2 = packed(w2, kActHid, kActHid, kActHid, 4), o_b2 = plain(b2, kActHid, kActHid);
+    const size_t o_w3 = packed(w3, kActHid, kActHid, kActHid, 4), o_b3 = plain(b3, kActHid, kActHid);
+    // heads: one 16-wide tile, columns mu0..2, log_std0..2, zeros: [8][64][4]
+    std::vector<float> wh((size_t)16 * kActHid, 0.0f);  // [n 16][k 128]
+    for (int o = 0; o < 3; o++)
+        for (int k = 0; k < kActHid; k++) {
+            wh[(size_t)o * kActHid + k] = w_mu[(size_t)o * kActHid + k];
+            wh[(size_t)(3 + o) * kActHid + k] = w_log_std[(size_t)o * kActHid + k];
         }
+    const size_t o_wh = h.size();
+    h.resize(o_wh + (size_t)8 * 64 * 4, 0.0f);
+    for (int g = 0; g < 8; g++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 4; j++)
+                h[o_wh + ((size_t)g * 64 + lane) * 4 + j] = wh[(size_t)(lane & 15) * kActHid + 4 * (4 * g + j) + (lane >> 4)];
     const size_t o_bh = h.size();
-    h.resize(o_bh + 8, 0.0f);
+    h.resize(o_bh + 16, 0.0f);
     for (int o = 0; o < 3; o++) { h[o_bh + o] = b_mu[o]; h[o_bh + 3 + o] = b_log_std[o]; }
+    if (h.size() > a->nfloat) {
+        a->err = "meshenv_actor_load: internal size mismatch";
+        return MESHENV_E_STATE;
+    }
     if (hipSetDevice(a->device) != hipSuccess ||
         hipMemcpy(a->buf, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         a->err = "meshenv_actor_load: upload failed";
         return MESHENV_E_HIP;
     }
-    a->W.w1t = a->buf + o_w1; a->W.b1 = a->buf + o_b1;
-    a->W.w2t = a->buf + o_w2; a->W.b2 = a->buf + o_b2;
-    a->W.w3t = a->buf + o_w3; a->W.b3 = a->buf + o_b3;
-    a->W.wht = a->buf + o_wh; a->W.bh = a->buf + o_bh;
+    a->W.w1p = a->buf + o_w1; a->W.b1 = a->buf + o_b1;
+    a->W.w2p = a->buf + o_w2; a->W.b2 = a->buf + o_b2;
+    a->W.w3p = a->buf + o_w3; a->W.b3 = a->buf + o_b3;
+    a->W.whp = a->buf + o_wh; a->W.bh = a->buf + o_bh;
     for (int i = 0; i < 3; i++) { a->W.low[i] = low[i]; a->W.high[i] = high[i]; }
     a->loaded = true;
     return MESHENV_OK;
