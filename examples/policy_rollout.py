@@ -27,8 +27,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--domain", default="d1", choices=["d1", "boundary0"])
     ap.add_argument("--deterministic", action="store_true")
-    ap.add_argument("--actor", default="fused", choices=["fused", "graph", "eager"],
-                    help="fused = the hand-written HIP actor kernel (one launch); graph = the torch MLP captured as one HIP "
+    ap.add_argument("--actor", default="fused", choices=["fused", "fused-ext-noise", "graph", "eager"],
+                    help="fused = the hand-written HIP actor kernel, exploration noise drawn inside it (one launch); "
+                         "fused-ext-noise = same kernel fed by torch's normal_() (two launches); graph = the torch MLP captured as one HIP "
                          "graph; eager = the torch MLP launch by launch")
     args = ap.parse_args()
     import torch
@@ -61,14 +62,20 @@ def main():
 
     env = MeshVecEnv([dom], n_envs=args.envs, device=0)
     obs = env.reset()          # env.obs: the kernel always writes observations into this tensor
-    if args.actor == "fused":
+    if args.actor.startswith("fused"):
         from reinforcementlearning4meshgeneration_amd.actor import FusedActor
         fused = FusedActor.from_torch([trunk[0], trunk[2], trunk[4]], mu_head, log_std_head)
         actions = torch.empty((args.envs, 3), dtype=torch.float32, device=dev)
         noise = torch.empty((args.envs, 3), dtype=torch.float32, device=dev)
+        draw = [0]
 
         def policy(o):
-            return fused.forward(o, None if args.deterministic else noise.normal_(), out=actions)
+            if args.deterministic:
+                return fused.forward(o, None, out=actions)
+            if args.actor == "fused":
+                draw[0] += 1
+                return fused.sample(o, 999, draw[0], out=actions)
+            return fused.forward(o, noise.normal_(), out=actions)
     elif args.actor == "graph":
         # ~25 tiny launches of the actor -> one graph replay; input = the env's observation buffer, output static
         side = torch.cuda.Stream()

@@ -244,6 +244,14 @@ int meshenv_actor_load(MeshActor *a, const float *w1, const float *b1, const flo
                        const float *b3, const float *w_mu, const float *b_mu, const float *w_log_std,
                        const float *b_log_std, const float *low, const float *high);
 int meshenv_actor_forward(MeshActor *a, int n, const float *obs_dev, const float *noise_dev, float *actions_dev);
+/*
+ * The stochastic action with the noise drawn inside the kernel: eps[env][k] is a standard normal from Philox4x32-10
+ * keyed by `seed` with counter (env, `counter`) and Box-Muller -- the caller passes a fresh `counter` per rollout step
+ * (same seed + counter -> same actions).  eps_out_dev [n,3] (nullable) receives the noise that was used, so that
+ * meshenv_actor_forward(obs, eps_out) reproduces the actions bit for bit.  Saves the separate random-number launch.
+ */
+int meshenv_actor_sample(MeshActor *a, int n, const float *obs_dev, uint64_t seed, uint64_t counter, float *actions_dev,
+                         float *eps_out_dev);
 
 /*
  * Test hook: evaluate one device geometry primitive on n items (in_per_item doubles each) and copy the results

@@ -37,7 +37,7 @@ EXPORTS = [
     "meshenv_step", "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",
     "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times", "meshenv_selftest", "meshenv_set_packed_output",
     "meshenv_actor_create", "meshenv_actor_destroy", "meshenv_actor_set_stream", "meshenv_actor_load",
-    "meshenv_actor_forward", "meshenv_get_last_episode", "meshenv_element_quality",
+    "meshenv_actor_forward", "meshenv_actor_sample", "meshenv_get_last_episode", "meshenv_element_quality",
 ]
 
 
@@ -97,7 +97,9 @@ def load():
     L.meshenv_actor_set_stream.argtypes = [vp, vp]
     L.meshenv_actor_load.argtypes = [vp] + [vp] * 12
     L.meshenv_actor_forward.argtypes = [vp, C.c_int, vp, vp, vp]
-    for name in ("meshenv_actor_create", "meshenv_actor_set_stream", "meshenv_actor_load", "meshenv_actor_forward"):
+    L.meshenv_actor_sample.argtypes = [vp, C.c_int, vp, C.c_uint64, C.c_uint64, vp, vp]
+    for name in ("meshenv_actor_create", "meshenv_actor_set_stream", "meshenv_actor_load", "meshenv_actor_forward",
+                 "meshenv_actor_sample"):
         getattr(L, name).restype = C.c_int
     for name in ("meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_reset", "meshenv_step",
                  "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",

@@ -62,6 +62,25 @@ class FusedActor:
             raise _capi.MeshEnvError(f"meshenv_actor_forward failed ({rc})")
         return out
 
+    def sample(self, obs, seed: int, counter: int, out=None, eps_out=None):
+        """Stochastic action with the N(0,1) exploration noise drawn inside the kernel (Philox4x32-10 keyed by `seed`,
+        counter (env, `counter`)): pass a fresh `counter` every rollout step.  eps_out (float32 CUDA [n,3], optional)
+        receives the noise used, so that forward(obs, eps_out) reproduces the actions exactly."""
+        t = self._torch
+        n = obs.shape[0]
+        if out is None:
+            out = t.empty((n, 3), dtype=t.float32, device=self.device)
+        stream = t.cuda.current_stream(self.device).cuda_stream
+        if stream != self._stream:
+            self._L.meshenv_actor_set_stream(self._h, C.c_void_p(stream))
+            self._stream = stream
+        rc = self._L.meshenv_actor_sample(self._h, n, obs.data_ptr(), C.c_uint64(seed & (2 ** 64 - 1)),
+                                          C.c_uint64(counter & (2 ** 64 - 1)), out.data_ptr(),
+                                          eps_out.data_ptr() if eps_out is not None else None)
+        if rc != 0:
+            raise _capi.MeshEnvError(f"meshenv_actor_sample failed ({rc})")
+        return out
+
     def close(self):
         if self._h:
             self._L.meshenv_actor_destroy(self._h)

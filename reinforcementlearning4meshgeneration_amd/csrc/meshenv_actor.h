@@ -38,6 +38,36 @@ struct ActorWeights {
     float low[3], high[3];
 };
 
+// Philox4x32-10 (Salmon et al., SC'11) keyed by the caller's seed, counter = (env, draw counter): the exploration
+// noise of SAC's actor without a separate random-number launch.  Returns four uniform 32-bit words.
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                           uint32_t out[4])
+{
+#pragma unroll
+    for (int round = 0; round < 10; round++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// standard normal number `which` (0..2) of environment `env` at draw `counter`: Box-Muller on two Philox words
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t counter, uint32_t env, int which)
+{
+    uint32_t r[4];
+    philox4x32(env, (uint32_t)counter, (uint32_t)(counter >> 32), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const uint32_t a = which < 2 ? r[0] : r[2], b = which < 2 ? r[1] : r[3];
+    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+    const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.2831853071795864f * u2, &sn, &cs);
+    return rad * (which == 1 ? sn : cs);
+}
+
 template <int G>  // G = K / 16 float4 groups per tile
 struct LayerRegs {
     f32x4 w[2][G];
@@ -85,7 +115,7 @@ __device__ __forceinline__ void actor_layer(const LayerRegs<G> &r, const float *
 
 __global__ void __launch_bounds__(256)
 k_actor_forward(ActorWeights W, int n, const float *__restrict__ obs, const float *__restrict__ noise,
-                float *__restrict__ actions)
+                float *__restrict__ actions, int sample, uint64_t seed, uint64_t counter, float *__restrict__ eps_out)
 {
     __shared__ __attribute__((aligned(16))) float bufA[kActEnvs * kActStride];
     __shared__ __attribute__((aligned(16))) float bufB[kActEnvs * kActStride];
@@ -96,6 +126,14 @@ k_actor_forward(ActorWeights W, int n, const float *__restrict__ obs, const floa
     LayerRegs<8> r2, r3;
     load_layer<2>(r1, W.w1p, wave, lane);
     load_layer<8>(r2, W.w2p, wave, lane);
+    // exploration noise, drawn while the weights are in flight: wave w draws row 4 q + w of every 4-row group
+    __shared__ float eps_lds[kActEnvs * 4];
+    if ((lane & 15) < kActOut && (noise || sample)) {
+        const int row = 4 * (lane >> 4) + wave, env = env0 + row;
+        float eps = 0.0f;
+        if (env < n) eps = sample ? philox_normal(seed, counter, (uint32_t)env, lane & 15) : noise[(size_t)env * 3 + (lane & 15)];
+        eps_lds[row * 4 + (lane & 15)] = eps;
+    }
     // observations -> bufA in the K = 32 layout (zero for k >= 18 and for envs past n)
     for (int i = t; i < kActEnvs * kActInPad; i += 256) {
         const int e = i >> 5, k = i & 31;
@@ -139,9 +177,11 @@ k_actor_forward(ActorWeights W, int n, const float *__restrict__ obs, const floa
         const int env = env0 + 4 * q + reg;
         if (e < kActOut && env < n) {
             float mu = v;
-            if (noise) {
+            if (noise || sample) {
+                const float eps = eps_lds[(4 * q + reg) * 4 + e];
+                if (eps_out) eps_out[(size_t)env * 3 + e] = eps;
                 const float ls = fminf(fmaxf(ls_raw, -20.0f), 2.0f);
-                mu += expf(ls) * noise[(size_t)env * 3 + e];
+                mu += expf(ls) * eps;
             }
             const float sq = tanhf(mu);
             actions[(size_t)env * 3 + e] = W.low[e] + 0.5f * (sq + 1.0f) * (W.high[e] - W.low[e]);

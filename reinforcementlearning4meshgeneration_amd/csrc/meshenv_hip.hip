@@ -732,20 +732,36 @@ int meshenv_actor_load(MeshActor *a, const float *w1, const float *b1, const flo
     return MESHENV_OK;
 }
 
-int meshenv_actor_forward(MeshActor *a, int n, const float *obs_dev, const float *noise_dev, float *actions_dev)
+static int actor_launch(MeshActor *a, const char *fn, int n, const float *obs_dev, const float *noise_dev,
+                        float *actions_dev, int sample, uint64_t seed, uint64_t counter, float *eps_out_dev)
 {
     if (!a || n <= 0 || !obs_dev || !actions_dev) return MESHENV_E_ARG;
     if (!a->loaded) {
-        a->err = "meshenv_actor_forward: no weights loaded";
+        a->err = std::string(fn) + ": no weights loaded";
         return MESHENV_E_STATE;
     }
+    if (hipSetDevice(a->device) != hipSuccess) {
+        a->err = std::string(fn) + ": hipSetDevice failed";
+        return MESHENV_E_HIP;
+    }
     hipLaunchKernelGGL(k_actor_forward, dim3((n + kActEnvs - 1) / kActEnvs), dim3(256), 0, a->stream, a->W, n, obs_dev, noise_dev,
-                       actions_dev);
+                       actions_dev, sample, seed, counter, eps_out_dev);
     if (hipGetLastError() != hipSuccess) {
-        a->err = "meshenv_actor_forward: launch failed";
+        a->err = std::string(fn) + ": launch failed";
         return MESHENV_E_HIP;
     }
     return MESHENV_OK;
+}
+
+int meshenv_actor_forward(MeshActor *a, int n, const float *obs_dev, const float *noise_dev, float *actions_dev)
+{
+    return actor_launch(a, "meshenv_actor_forward", n, obs_dev, noise_dev, actions_dev, 0, 0, 0, nullptr);
+}
+
+int meshenv_actor_sample(MeshActor *a, int n, const float *obs_dev, uint64_t seed, uint64_t counter, float *actions_dev,
+                         float *eps_out_dev)
+{
+    return actor_launch(a, "meshenv_actor_sample", n, obs_dev, nullptr, actions_dev, 1, seed, counter, eps_out_dev);
 }
 
 }  // extern "C"

@@ -44,3 +44,35 @@ def test_fused_actor_matches_torch(n):
     assert float((sto - ref_sto).abs().max()) <= 2e-5
     assert bool(((det >= low) & (det <= high)).all())
     actor.close()
+
+
+def test_in_kernel_noise_is_reproducible_and_standard_normal():
+    """meshenv_actor_sample: (seed, counter) -> the same actions; the returned eps fed to the explicit-noise entry
+    point reproduces them bit for bit; eps is N(0,1) (moments, tails, independence across envs / components / draws)."""
+    import torch
+
+    from reinforcementlearning4meshgeneration_amd.actor import FusedActor
+    lin, mu, ls = _net(torch, 7)
+    actor = FusedActor.from_torch(lin, mu, ls)
+    n = 100000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    obs = (torch.rand((n, 18), device="cuda", generator=g) * 4 - 1).float()
+    eps = torch.empty((n, 3), device="cuda")
+    a1 = actor.sample(obs, seed=1234, counter=5, eps_out=eps).clone()
+    a2 = actor.sample(obs, seed=1234, counter=5).clone()
+    assert torch.equal(a1, a2)
+    assert torch.equal(actor.forward(obs, eps), a1)
+    eps2 = torch.empty((n, 3), device="cuda")
+    a3 = actor.sample(obs, seed=1234, counter=6, eps_out=eps2)
+    assert not torch.equal(a3, a1)
+    e = eps.double().cpu().numpy()
+    e2 = eps2.double().cpu().numpy()
+    assert np.isfinite(e).all()
+    assert abs(e.mean()) < 0.01 and abs(e.std() - 1) < 0.01
+    assert abs((e ** 3).mean()) < 0.03 and abs((e ** 4).mean() - 3) < 0.08          # skewness, kurtosis
+    assert abs(np.mean(np.abs(e) > 1.959964) - 0.05) < 0.003                         # two-sided 5 % tail
+    c = np.corrcoef(np.concatenate([e, e2], axis=1).T)                               # components x draws
+    assert np.abs(c - np.eye(6)).max() < 0.01
+    assert abs(np.corrcoef(e[:-1, 0], e[1:, 0])[0, 1]) < 0.01                        # neighbouring envs
+    actor.close()
