@@ -1294,6 +1294,11 @@ k_step_group(DevState S, int cap, const float *__restrict__ actions, float *__re
     const int env = blockIdx.x * G + wave;
     const bool active = env < S.n_envs;
     int pending = 0;
+#ifdef MESHENV_STAMPS
+    // diagnostic build (tools/group_timeline.py, tools/group_phase2_timeline.py): dbg[env][0..5] describe the wave
+    // that owns env in phase 1, dbg[env][6..15] the phase-2 update of env (whichever wave ran it)
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (active) {
         Ctx c;
         carve_lds(c, (char *)smem + (size_t)wave * env_bytes, cap);
@@ -1321,7 +1326,18 @@ k_step_group(DevState S, int cap, const float *__restrict__ actions, float *__re
         ho[wave].valid = pending;
         ho[wave].simd = (int)__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11));  // HW_REG_HW_ID.simd_id
     }
+#ifdef MESHENV_STAMPS
+    const unsigned long long dbg_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
     __syncthreads();
+#ifdef MESHENV_STAMPS
+    const unsigned long long dbg_t2 = __builtin_amdgcn_s_memrealtime();
+    if (active && (threadIdx.x & 63) == 0) {
+        unsigned long long *o = S.dbg + (size_t)env * 16;
+        o[0] = dbg_t0; o[1] = dbg_t1; o[2] = dbg_t2; o[3] = (unsigned long long)pending; o[4] = 0; o[5] = 0;
+        if (!pending) o[15] = 0;
+    }
+#endif
 
     // ---- deal the pending updates over the SIMDs
     unsigned vmask = 0, smask[4] = {0, 0, 0, 0};
@@ -1375,7 +1391,23 @@ k_step_group(DevState S, int cap, const float *__restrict__ actions, float *__re
     const EnvCounters cnt0 = h.cnt0;
     const int n_before = c.n;
     env_apply(c, S, d);
+#ifdef MESHENV_STAMPS
+    const unsigned long long dbg_t8 = __builtin_amdgcn_s_memrealtime();
+#endif
     finish_and_store(c, S, d, cnt0, n_before, obs_out, reward, done, complete, term_obs, auto_reset);
+#ifdef MESHENV_STAMPS
+    if (c.lane == 0) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *o = S.dbg + (size_t)c.env * 16;
+        o[6] = c.sc->stamps[6]; o[7] = dbg_t2; o[8] = dbg_t8;
+        for (int k = 9; k <= 14; k++) o[k] = c.sc->stamps[k];
+        o[15] = t_end;
+        if (active) {
+            unsigned long long *w = S.dbg + (size_t)env * 16;
+            w[4] = t_end; w[5] = (unsigned long long)(src + 1);
+        }
+    }
+#endif
 }
 
 }  // namespace meshenv
