@@ -97,6 +97,24 @@ class BoudaryEnv:  # the reference's spelling
         """(quads [n,4] vertex ids, vertices [m,2]) -- what write_generated_elements_2_file consumes."""
         return self._vec.get_elements(0)
 
+    def write_generated_elements_2_file(self, filename):
+        """Abaqus .inp of the current episode's mesh (general/mesh.py:1842-1864); byte-identical to the reference's file."""
+        from .export import write_inp
+        quads, vxy = self._vec.get_elements(0)
+        write_inp(filename, quads, vxy, self.points)
+
+    def write_2_file(self, filename):
+        """JSON node / element dump (rl/boundary_env.py:648-669)."""
+        from .export import write_2_file
+        quads, vxy = self._vec.get_elements(0)
+        write_2_file(filename, quads, vxy, self.points)
+
+    def element_quality(self):
+        """[n_elem, 8] float64: min / max corner angle (deg), scaled Jacobian, stretch, taper, robust, area, default
+        -- Mesh.get_quality(type) of every generated element (general/components.py:863-950), computed on the GPU."""
+        rec, _, cnt = self._vec.element_quality("current")
+        return rec[0, :int(cnt[0])].cpu().numpy()
+
     @property
     def failed_num(self):
         return self._vec.get_state(0)["failed_num"]

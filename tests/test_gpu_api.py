@@ -187,4 +187,14 @@ def test_inp_export_equals_reference_file():
     quads, vxy = env.get_elements()
     assert len(quads) == fx["n_elements"]
     assert inp_text(quads, vxy, pts) == fx["inp"]
+    # the reference's own method names on the drop-in class
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        env.write_generated_elements_2_file(os.path.join(tmp, "m.inp"))
+        assert open(os.path.join(tmp, "m.inp")).read() == fx["inp"]
+        env.write_2_file(os.path.join(tmp, "m.json"))
+        dumped = json.load(open(os.path.join(tmp, "m.json")))
+        assert len(dumped["elements"]) == fx["n_elements"] and len(dumped["nodes"]) == len(vxy)
+    q = env.element_quality()
+    assert q.shape == (fx["n_elements"], 8) and np.isfinite(q).all() and (q[:, 3] > 0).all() and (q[:, 3] <= 1 + 1e-12).all()
     env.close()
