@@ -185,11 +185,14 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
     } while (0)
 
     CREATE_HIP(hipSetDevice(device));
+    // The attribute is per function, not per handle: always raise it to the CU's full 160 KB so that a later handle with
+    // shorter rings cannot lower the cap under an earlier one.
+    constexpr int kLdsCap = 160 * 1024;
     if (lds > 64 * 1024) {
-        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CREATE_HIP(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CREATE_HIP(hipFuncSetAttribute((const void *)k_init_domains, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_init_domains, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
     }
 
     // Single-step kernel variant.  The CU-group kernel (G envs per workgroup, SIMD-balanced updates) pays off in the
@@ -213,7 +216,7 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
         h->group_lds = group_lds_bytes(cap, G);
         if (G > 1 && h->group_lds > 64 * 1024) {
             const void *fn = G == 16 ? (const void *)k_step_group<16> : G == 8 ? (const void *)k_step_group<8> : (const void *)k_step_group<4>;
-            CREATE_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->group_lds));
+            CREATE_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         }
     }
 

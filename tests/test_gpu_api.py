@@ -198,3 +198,33 @@ def test_inp_export_equals_reference_file():
     q = env.element_quality()
     assert q.shape == (fx["n_elements"], 8) and np.isfinite(q).all() and (q[:, 3] > 0).all() and (q[:, 3] <= 1 + 1e-12).all()
     env.close()
+
+
+def test_two_handles_with_different_ring_sizes_coexist():
+    """Dynamic-LDS caps are per kernel function, not per handle: a long-ring handle (> 64 KB of LDS per wave) must keep
+    working after a short-ring handle has been created, and both must keep matching the oracle."""
+    import torch
+    from oracle.ref_lib import RefEnv
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv, boundary
+
+    def zigzag(n, r):
+        t = -2 * np.pi * np.arange(n) / n
+        rr = r + 0.08 * (-1.0) ** np.arange(n)
+        return [(round(float(x), 4), round(float(y), 4)) for x, y in zip(rr * np.cos(t), rr * np.sin(t))]
+
+    big = zigzag(2000, 95.0)
+    e_big = MeshVecEnv([big], n_envs=4, auto_reset=False)
+    e_small = MeshVecEnv([boundary(0)], n_envs=4, auto_reset=False)
+    refs = [RefEnv.from_points(big), RefEnv.from_points(boundary(0))]
+    envs = [e_big, e_small]
+    for e, r in zip(envs, refs):
+        np.testing.assert_array_equal(e.reset().cpu().numpy()[0], r.reset()[0])
+    rng = np.random.default_rng(2)
+    for t in range(30):
+        a = np.array([rng.uniform(-1, 1), rng.uniform(0.2, 1.0), rng.uniform(0.3, 1.2)], np.float32)
+        for e, r in zip(envs, refs):
+            o, rew, d, c = e.step(torch.from_numpy(np.tile(a, (4, 1))).cuda())
+            o_ref, r_ref, d_ref, c_ref, _ = r.step(a)
+            assert np.abs(o.cpu().numpy()[0].astype(np.float64) - o_ref).max() <= 1e-5
+            assert abs(float(rew.cpu()[0]) - r_ref) <= 1e-5 and bool(d.cpu()[0]) == bool(d_ref)
+    e_big.close(); e_small.close()
