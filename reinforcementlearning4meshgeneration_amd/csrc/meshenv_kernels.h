@@ -1288,7 +1288,7 @@ k_step_group(DevState S, int cap, const float *__restrict__ actions, float *__re
              float *__restrict__ term_obs, int auto_reset)
 {
     extern __shared__ double2 smem[];
-    const int wave = threadIdx.x >> 6;
+    const int wave = uniform_i32((int)(threadIdx.x >> 6));  // wave-uniform by construction: keeps env and every address derived from it in SGPRs
     const size_t env_bytes = lds_bytes_for(cap);
     Handoff *ho = (Handoff *)((char *)smem + (size_t)G * env_bytes);
     const int env = blockIdx.x * G + wave;
