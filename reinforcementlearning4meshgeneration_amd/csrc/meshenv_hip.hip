@@ -29,6 +29,7 @@ struct MeshEnv {
     hipStream_t stream = nullptr;
     DevState S{};
     int n_envs = 0, n_domains = 0, cap = 0, max_ring = 0;
+    bool default_params = true;  // geometry constants are the reference's: literal-constant kernel instantiations
     size_t lds = 0;
     int group = 1;        // environments (wavefronts) per workgroup of the single-step kernel
     size_t group_lds = 0;
@@ -87,13 +88,13 @@ void meshenv_default_params(MeshEnvParams *p)
     p->radius_num = 3;
     p->fail_limit = 100;
     p->log_capacity = 0;
-    p->radius = 4;
-    p->max_ref_angle = kPi * 0.972;
-    p->key_lambda = 0.618;
-    p->min_degree = 0.01 * kPi;
-    p->max_degree = 0.99 * kPi;
-    p->same_point_eps = 0.001;
-    p->ray_length = 10000;
+    p->radius = kDefRadius;
+    p->max_ref_angle = kDefMaxRefAngle;
+    p->key_lambda = kDefKeyLambda;
+    p->min_degree = kDefMinDegree;
+    p->max_degree = kDefMaxDegree;
+    p->same_point_eps = kDefSameEps;
+    p->ray_length = kDefRayLength;
 }
 
 int meshenv_abi_version(void) { return MESHENV_ABI_VERSION; }
@@ -189,8 +190,10 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
     // shorter rings cannot lower the cap under an earlier one.
     constexpr int kLdsCap = 160 * 1024;
     if (lds > 64 * 1024) {
-        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
-        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_init_domains, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
     }
@@ -212,10 +215,16 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
         for (int g : {16, 8, 4})
             if (g <= want && group_lds_bytes(cap, g) <= 150 * 1024) { G = g; break; }
         if (!force && (G < 8 || n_envs > 256 * G)) G = 1;  // LDS forced a smaller group: more than one workgroup per CU
+        MeshEnvParams def;
+        meshenv_default_params(&def);
+        h->default_params = prm.radius == def.radius && prm.max_ref_angle == def.max_ref_angle && prm.key_lambda == def.key_lambda &&
+                            prm.min_degree == def.min_degree && prm.max_degree == def.max_degree &&
+                            prm.same_point_eps == def.same_point_eps && prm.ray_length == def.ray_length;
+        if (!h->default_params) G = 1;  // the group kernels exist with literal (default) geometry constants only
         h->group = G;
         h->group_lds = group_lds_bytes(cap, G);
         if (G > 1 && h->group_lds > 64 * 1024) {
-            const void *fn = G == 16 ? (const void *)k_step_group<16> : G == 8 ? (const void *)k_step_group<8> : (const void *)k_step_group<4>;
+            const void *fn = G == 16 ? (const void *)k_step_group<16, true> : G == 8 ? (const void *)k_step_group<8, true> : (const void *)k_step_group<4, true>;
             CREATE_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         }
     }
@@ -338,20 +347,28 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         const int G = h->group;
         const dim3 grid((h->n_envs + G - 1) / G), block(64 * G);
         if (G == 16)
-            hipLaunchKernelGGL(k_step_group<16>, grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
+            hipLaunchKernelGGL((k_step_group<16, true>), grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
                                reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
         else if (G == 8)
-            hipLaunchKernelGGL(k_step_group<8>, grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
+            hipLaunchKernelGGL((k_step_group<8, true>), grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
                                reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
         else
-            hipLaunchKernelGGL(k_step_group<4>, grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
+            hipLaunchKernelGGL((k_step_group<4, true>), grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
                                reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
-    } else if (n_steps == 1)
-        hipLaunchKernelGGL(k_step<false>, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, 1, actions_dev, obs_dev,
-                           reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
-    else
-        hipLaunchKernelGGL(k_step<true>, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, n_steps, actions_dev, obs_dev,
-                           reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
+    } else {
+        const dim3 grid(h->n_envs), block(64);
+#define MESHENV_LAUNCH_STEP(MULTI, DEF)                                                                                      \
+    hipLaunchKernelGGL((k_step<MULTI, DEF>), grid, block, h->lds, h->stream, h->S, h->cap, n_steps, actions_dev, obs_dev,   \
+                       reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset)
+        if (n_steps == 1) {
+            if (h->default_params) MESHENV_LAUNCH_STEP(false, true);
+            else MESHENV_LAUNCH_STEP(false, false);
+        } else {
+            if (h->default_params) MESHENV_LAUNCH_STEP(true, true);
+            else MESHENV_LAUNCH_STEP(true, false);
+        }
+#undef MESHENV_LAUNCH_STEP
+    }
     HIP_TRY(h, hipGetLastError());
     if (pos >= 0 && pos == h->timing - 1) {
         HIP_TRY(h, hipEventRecord(h->ev[2 * slot + 1], h->stream));

@@ -114,14 +114,20 @@ __device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env)
     // everything below is independent: one HBM round trip
     const EnvScalars s = S.scal[env];
     const int first = S.cap < 64 ? S.cap : 64;
+    // per-env base pointers are wave-uniform (SGPR pairs); the lane index stays a 32-bit offset
+    const double2 *gxy = S.ring_xy + c.base;
+    const int32_t *gid = S.ring_id + c.base;
+    const double *gkey = S.ring_key + c.base;
+    const int32_t *gst = S.ring_stamp + c.base;
+    const unsigned ul = (unsigned)lane;
     double2 v_xy = make_double2(0, 0);
     double v_key = 0;
     int v_id = 0, v_st = kNotCand;
     if (lane < first) {
-        v_xy = S.ring_xy[c.base + lane];
-        v_id = S.ring_id[c.base + lane];
-        v_key = S.ring_key[c.base + lane];
-        v_st = S.ring_stamp[c.base + lane];
+        v_xy = gxy[ul];
+        v_id = gid[ul];
+        v_key = gkey[ul];
+        v_st = gst[ul];
     }
     c.obs = lane < kObsDim ? S.obs_cache[(size_t)env * kObsDim + lane] : 0.0f;
     c.n = uniform_i32(s.n); c.ref = uniform_i32(s.ref); c.n_elem = uniform_i32(s.n_elem);
@@ -135,11 +141,11 @@ __device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env)
         c.key[lane] = v_key;
         c.stamp[lane] = v_st;
     }
-    for (int i = 64 + lane; i < c.n; i += 64) {
-        c.xy[i] = S.ring_xy[c.base + i];
-        c.id[i] = S.ring_id[c.base + i];
-        c.key[i] = S.ring_key[c.base + i];
-        c.stamp[i] = S.ring_stamp[c.base + i];
+    for (unsigned i = 64u + ul; i < (unsigned)c.n; i += 64u) {
+        c.xy[i] = gxy[i];
+        c.id[i] = gid[i];
+        c.key[i] = gkey[i];
+        c.stamp[i] = gst[i];
     }
     wave_sync();
 }
@@ -148,11 +154,15 @@ __device__ __forceinline__ void store_env(Ctx &c, const DevState &S)
 {
     wave_sync();
     if (c.ring_dirty) {
-        for (int i = c.lane; i < c.n; i += 64) {
-            S.ring_xy[c.base + i] = c.xy[i];
-            S.ring_id[c.base + i] = c.id[i];
-            S.ring_key[c.base + i] = c.key[i];
-            S.ring_stamp[c.base + i] = c.stamp[i];
+        double2 *gxy = S.ring_xy + c.base;
+        int32_t *gid = S.ring_id + c.base;
+        double *gkey = S.ring_key + c.base;
+        int32_t *gst = S.ring_stamp + c.base;
+        for (unsigned i = (unsigned)c.lane; i < (unsigned)c.n; i += 64u) {
+            gxy[i] = c.xy[i];
+            gid[i] = c.id[i];
+            gkey[i] = c.key[i];
+            gst[i] = c.stamp[i];
         }
         if (c.lane < kObsDim) S.obs_cache[(size_t)c.env * kObsDim + c.lane] = c.obs;
     }
@@ -1146,13 +1156,14 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
 #ifndef MESHENV_STEP_WAVES_PER_SIMD
 #define MESHENV_STEP_WAVES_PER_SIMD 4
 #endif
-template <bool kMulti>
+template <bool kMulti, bool kDefaultParams>
 __global__ void __launch_bounds__(64, MESHENV_STEP_WAVES_PER_SIMD)
 k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, float *__restrict__ obs_out,
        double *__restrict__ reward, uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
        float *__restrict__ term_obs, int auto_reset)
 {
     extern __shared__ double2 smem[];
+    if (kDefaultParams) apply_default_params(S.prm);
     Ctx c;
     carve_lds(c, smem, cap);
     const int env = blockIdx.x;
@@ -1281,13 +1292,14 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
 // UPDATES are dealt round-robin over the four SIMDs of the CU (phase 2): wave (simd s, r-th on that SIMD) takes the
 // (4r+s)-th pending env of the group.  The env's ring never moves -- it is already in the workgroup's LDS -- only
 // ~40 scalars are handed over (Handoff).  Environments stay independent: no data is shared between envs.
-template <int G>
+template <int G, bool kDefaultParams>
 __global__ void __launch_bounds__(64 * G)
 k_step_group(DevState S, int cap, const float *__restrict__ actions, float *__restrict__ obs_out,
              double *__restrict__ reward, uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
              float *__restrict__ term_obs, int auto_reset)
 {
     extern __shared__ double2 smem[];
+    if (kDefaultParams) apply_default_params(S.prm);
     const int wave = uniform_i32((int)(threadIdx.x >> 6));  // wave-uniform by construction: keeps env and every address derived from it in SGPRs
     const size_t env_bytes = lds_bytes_for(cap);
     Handoff *ho = (Handoff *)((char *)smem + (size_t)G * env_bytes);

@@ -54,6 +54,19 @@ struct Params {
     int fail_limit, log_cap;
 };
 
+// The reference's constants (rl/boundary_env.py:26-56, general/mesh.py:26-28, components.py:721-722).  Handles created
+// with exactly these values run kernel instantiations in which they are literals (kDefaultParams): eight doubles leave
+// the scalar registers and x / radius becomes an exact multiplication.
+constexpr double kDefPi = 3.141592653589793;
+constexpr double kDefRadius = 4.0, kDefMaxRefAngle = kDefPi * 0.972, kDefKeyLambda = 0.618;
+constexpr double kDefMinDegree = 0.01 * kDefPi, kDefMaxDegree = 0.99 * kDefPi, kDefSameEps = 0.001, kDefRayLength = 10000.0;
+
+__host__ __device__ inline void apply_default_params(Params &p)
+{
+    p.radius = kDefRadius; p.max_ref_angle = kDefMaxRefAngle; p.w0 = kDefKeyLambda; p.w1 = 1 - kDefKeyLambda;
+    p.min_degree = kDefMinDegree; p.max_degree = kDefMaxDegree; p.same_eps = kDefSameEps; p.ray_length = kDefRayLength;
+}
+
 constexpr int kNewBit = 0x40000000;  // ring_id of the k-th vertex created this episode = kNewBit | k
 
 struct LastEpisode {

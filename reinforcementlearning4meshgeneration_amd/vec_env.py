@@ -78,11 +78,14 @@ class MeshVecEnv:
     env_domain   domain index per env (default: env k uses domain k % len(domains))
     device       CUDA/HIP device index
     log_capacity elements / new vertices logged per env per episode (needed for ``generated_meshes``)
+    params       overrides of the geometry constants in MeshEnvParams (radius, max_ref_angle, key_lambda, min_degree,
+                 max_degree, same_point_eps, ray_length); the reference's values are the default and the fast path
     """
 
     def __init__(self, domains: Sequence[Sequence[Point]], n_envs: Optional[int] = None,
                  env_domain: Optional[Sequence[int]] = None, device: int = 0, log_capacity: int = 0,
-                 auto_reset: bool = True, fail_limit: int = 100, lazy_infos: bool = True):
+                 auto_reset: bool = True, fail_limit: int = 100, lazy_infos: bool = True,
+                 params: Optional[dict] = None):
         import torch
 
         self._torch = torch
@@ -114,6 +117,10 @@ class MeshVecEnv:
         prm = _capi.default_params()
         prm.log_capacity = self.log_capacity
         prm.fail_limit = int(fail_limit)
+        for k, v in (params or {}).items():
+            if k not in ("radius", "max_ref_angle", "key_lambda", "min_degree", "max_degree", "same_point_eps", "ray_length"):
+                raise ValueError(f"unknown MeshEnvParams field {k!r}")
+            setattr(prm, k, float(v))
         self._handle = C.c_void_p()
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
