@@ -29,6 +29,7 @@ struct MeshEnv {
     hipStream_t stream = nullptr;
     DevState S{};
     int n_envs = 0, n_domains = 0, cap = 0, max_ring = 0;
+    DevCold cold{};  // host copy of *S.cold
     bool default_params = true;  // geometry constants are the reference's: literal-constant kernel instantiations
     size_t lds = 0;
     int group = 1;        // environments (wavefronts) per workgroup of the single-step kernel
@@ -250,11 +251,13 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
     S.cap = cap;
 
     double2 *d_dom_xy = nullptr;
+    DevCold &K = h->cold;  // host copy of the rarely used pointers; the kernels read the device copy S.cold
+    std::memset(&K, 0, sizeof(K));
     CREATE_TRY(dev_alloc(h, &S.dom, (size_t)n_domains));
     CREATE_TRY(dev_alloc(h, &d_dom_xy, (size_t)total_dom));
-    CREATE_TRY(dev_alloc(h, &S.dom_key, (size_t)total_dom));
-    CREATE_TRY(dev_alloc(h, &S.dom_stamp, (size_t)total_dom));
-    CREATE_TRY(dev_alloc(h, &S.dom_obs, (size_t)n_domains * kObsDim));
+    CREATE_TRY(dev_alloc(h, &K.dom_key, (size_t)total_dom));
+    CREATE_TRY(dev_alloc(h, &K.dom_stamp, (size_t)total_dom));
+    CREATE_TRY(dev_alloc(h, &K.dom_obs, (size_t)n_domains * kObsDim));
     CREATE_TRY(dev_alloc(h, &S.ring_xy, total_env));
     CREATE_TRY(dev_alloc(h, &S.ring_id, total_env));
     CREATE_TRY(dev_alloc(h, &S.ring_key, total_env));
@@ -263,12 +266,18 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
     CREATE_TRY(dev_alloc(h, &S.cnt, (size_t)n_envs));
     CREATE_TRY(dev_alloc(h, &S.obs_cache, (size_t)n_envs * kObsDim));
     if (prm.log_capacity > 0) {
-        CREATE_TRY(dev_alloc(h, &S.log_quads, (size_t)n_envs * 2 * prm.log_capacity * 4));
-        CREATE_TRY(dev_alloc(h, &S.log_vxy, (size_t)n_envs * 2 * prm.log_capacity));
-        CREATE_TRY(dev_alloc(h, &S.last_ep, (size_t)n_envs));
-        CREATE_HIP(hipMemsetAsync(S.last_ep, 0, sizeof(LastEpisode) * (size_t)n_envs, h->stream));
+        CREATE_TRY(dev_alloc(h, &K.log_quads, (size_t)n_envs * 2 * prm.log_capacity * 4));
+        CREATE_TRY(dev_alloc(h, &K.log_vxy, (size_t)n_envs * 2 * prm.log_capacity));
+        CREATE_TRY(dev_alloc(h, &K.last_ep, (size_t)n_envs));
+        CREATE_HIP(hipMemsetAsync(K.last_ep, 0, sizeof(LastEpisode) * (size_t)n_envs, h->stream));
     }
-    S.dom_xy = d_dom_xy;
+    K.dom_xy = d_dom_xy;
+    {
+        DevCold *cold_dev = nullptr;
+        CREATE_TRY(dev_alloc(h, &cold_dev, (size_t)1));
+        CREATE_HIP(hipMemcpy(cold_dev, &K, sizeof(DevCold), hipMemcpyHostToDevice));
+        S.cold = cold_dev;
+    }
 #ifdef MESHENV_STAMPS
     CREATE_TRY(dev_alloc(h, &S.dbg, (size_t)n_envs * 16));
 #endif
@@ -473,7 +482,7 @@ static int fetch_elements(MeshEnv *h, const char *fn, int which, int env, int32_
     int half = (s.status >> 4) & 1, ne = s.n_elem, nnew = s.n_new;
     if (which) {
         LastEpisode le;
-        HIP_TRY(h, hipMemcpy(&le, h->S.last_ep + env, sizeof(le), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(&le, h->cold.last_ep + env, sizeof(le), hipMemcpyDeviceToHost));
         half ^= 1; ne = le.n_elem; nnew = le.n_new;
         if (flags) *flags = le.flags;
         if (episodes) *episodes = le.episodes;
@@ -487,15 +496,15 @@ static int fetch_elements(MeshEnv *h, const char *fn, int which, int env, int32_
     if (nv > cap_verts) nv = cap_verts;
     const size_t base = ((size_t)env * 2 + half) * cap;
     if (quads_host && ne > 0) {
-        HIP_TRY(h, hipMemcpy(quads_host, h->S.log_quads + base * 4, sizeof(int32_t) * 4 * (size_t)ne, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(quads_host, h->cold.log_quads + base * 4, sizeof(int32_t) * 4 * (size_t)ne, hipMemcpyDeviceToHost));
         for (int i = 0; i < 4 * ne; i++)
             if (quads_host[i] & kNewBit) quads_host[i] = n0 + (quads_host[i] & ~kNewBit);
     }
     if (vertex_xy_host && nv > 0) {
         const int first = nv < n0 ? nv : n0;
-        HIP_TRY(h, hipMemcpy(vertex_xy_host, h->S.dom_xy + h->dom_off_host[d], sizeof(double2) * (size_t)first, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(vertex_xy_host, h->cold.dom_xy + h->dom_off_host[d], sizeof(double2) * (size_t)first, hipMemcpyDeviceToHost));
         if (nv > n0)
-            HIP_TRY(h, hipMemcpy(vertex_xy_host + 2 * (size_t)n0, h->S.log_vxy + base, sizeof(double2) * (size_t)(nv - n0), hipMemcpyDeviceToHost));
+            HIP_TRY(h, hipMemcpy(vertex_xy_host + 2 * (size_t)n0, h->cold.log_vxy + base, sizeof(double2) * (size_t)(nv - n0), hipMemcpyDeviceToHost));
     }
     *n_elem = ne;
     *n_vert = nv;

@@ -722,19 +722,21 @@ __device__ __forceinline__ void reset_from_domain(Ctx &c, const DevState &S)
             le.n_elem = c.n_elem;
             le.n_new = c.n_new;
             le.flags = (c.n <= 5 ? 1 : 0) | (c.status & kStLogOverflow);
-            le.episodes = S.last_ep[c.env].episodes + 1;
-            S.last_ep[c.env] = le;
+            LastEpisode *last_ep = load_cold(S).last_ep;
+            le.episodes = last_ep[c.env].episodes + 1;
+            last_ep[c.env] = le;
         }
         half ^= kStLogHalf;
     }
     const DomConst dc = S.dom[c.dom];
+    const DevCold cold = load_cold(S);
     const int doff = uniform_i32(dc.off), n0 = uniform_i32(dc.n0);
     wave_sync();
     for (int i = c.lane; i < n0; i += 64) {
-        c.xy[i] = S.dom_xy[doff + i];
+        c.xy[i] = cold.dom_xy[doff + i];
         c.id[i] = i;
-        c.key[i] = S.dom_key[doff + i];
-        c.stamp[i] = S.dom_stamp[doff + i];
+        c.key[i] = cold.dom_key[doff + i];
+        c.stamp[i] = cold.dom_stamp[doff + i];
     }
     c.n = n0;
     c.ref = uniform_i32(dc.ref);
@@ -744,7 +746,7 @@ __device__ __forceinline__ void reset_from_domain(Ctx &c, const DevState &S)
     c.area = uniform_f64(dc.orig_area);
     c.n_elem = 0; c.failed = 0; c.n_new = 0; c.counter = 0;
     c.status = (c.ref < 0 ? kStNoReference : 0) | half;
-    c.obs = c.lane < kObsDim ? S.dom_obs[(size_t)c.dom * kObsDim + c.lane] : 0.0f;
+    c.obs = c.lane < kObsDim ? cold.dom_obs[(size_t)c.dom * kObsDim + c.lane] : 0.0f;
     c.ring_dirty = true;
     wave_sync();
 }
@@ -754,7 +756,7 @@ __device__ __forceinline__ void log_quad(Ctx &c, const DevState &S, int g0, int 
     const int cap = S.prm.log_cap;
     if (c.n_elem < cap) {
         if (c.lane == 0) {
-            int32_t *dst = S.log_quads + (((size_t)c.env * 2 + ((c.status >> 4) & 1)) * cap + c.n_elem) * 4;
+            int32_t *dst = load_cold(S).log_quads + (((size_t)c.env * 2 + ((c.status >> 4) & 1)) * cap + c.n_elem) * 4;
             dst[0] = g0; dst[1] = g1; dst[2] = g2; dst[3] = g3;
         }
     } else if (cap > 0) {
@@ -971,7 +973,7 @@ __device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d
             c.id[index] = kNewBit | c.n_new;
             c.stamp[index] = kNotCand;
             const int cap = prm.log_cap;
-            if (c.n_new < cap) S.log_vxy[((size_t)c.env * 2 + ((c.status >> 4) & 1)) * cap + c.n_new] = make_double2(d.new_point.x, d.new_point.y);
+            if (c.n_new < cap) load_cold(S).log_vxy[((size_t)c.env * 2 + ((c.status >> 4) & 1)) * cap + c.n_new] = make_double2(d.new_point.x, d.new_point.y);
         }
         if (prm.log_cap > 0 && c.n_new >= prm.log_cap) c.status |= kStLogOverflow;
         c.n_new += 1;
@@ -1078,6 +1080,7 @@ __global__ void __launch_bounds__(64) k_init_domains(DevState S, int cap)
     c.base = 0;
     c.dom = d;
     const DomConst dc = S.dom[d];
+    const DevCold cold = load_cold(S);
     const int doff = dc.off;
     c.n = dc.n0;
     c.area = dc.orig_area;
@@ -1085,7 +1088,7 @@ __global__ void __launch_bounds__(64) k_init_domains(DevState S, int cap)
     c.bl = 0.0; c.ct = 1.0; c.st = 0.0;
     c.obs = 0.0f;
     for (int i = c.lane; i < c.n; i += 64) {
-        c.xy[i] = S.dom_xy[doff + i];
+        c.xy[i] = cold.dom_xy[doff + i];
         c.id[i] = i;
     }
     wave_sync();
@@ -1104,10 +1107,10 @@ __global__ void __launch_bounds__(64) k_init_domains(DevState S, int cap)
     bq.mode = 0; bq.a = 0; bq.b = 0; bq.ang0 = 0; bq.ang1 = 0; bq.q_ang0 = 0; bq.q_ang2 = 0; bq.half01 = 0; bq.half23 = 0;
     find_next_state(c, S, bq);
     for (int i = c.lane; i < c.n; i += 64) {
-        S.dom_key[doff + i] = c.key[i];
-        S.dom_stamp[doff + i] = c.stamp[i];
+        cold.dom_key[doff + i] = c.key[i];
+        cold.dom_stamp[doff + i] = c.stamp[i];
     }
-    if (c.lane < kObsDim) S.dom_obs[(size_t)d * kObsDim + c.lane] = c.obs;
+    if (c.lane < kObsDim) cold.dom_obs[(size_t)d * kObsDim + c.lane] = c.obs;
     if (c.lane == 0) {
         S.dom[d].ref = c.ref;
         S.dom[d].bl = c.bl;

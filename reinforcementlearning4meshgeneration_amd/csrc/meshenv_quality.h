@@ -108,16 +108,17 @@ k_element_quality(DevState S, int which, double *__restrict__ elem_out, double *
     const int env = blockIdx.x, lane = lane_id();
     const int cap = S.prm.log_cap;
     const EnvScalars sc = S.scal[env];
+    const DevCold cold = load_cold(S);
     int half = (uniform_i32(sc.status) >> 4) & 1;
     int ne = uniform_i32(sc.n_elem);
     if (which) {
-        ne = uniform_i32(S.last_ep[env].n_elem);
+        ne = uniform_i32(cold.last_ep[env].n_elem);
         half ^= 1;
     }
     ne = ne < cap ? ne : cap;
     const int doff = uniform_i32(S.dom[uniform_i32(sc.dom)].off);
-    const int4 *quads = reinterpret_cast<const int4 *>(S.log_quads + ((size_t)env * 2 + half) * cap * 4);
-    const double2 *vnew = S.log_vxy + ((size_t)env * 2 + half) * cap;
+    const int4 *quads = reinterpret_cast<const int4 *>(cold.log_quads + ((size_t)env * 2 + half) * cap * 4);
+    const double2 *vnew = cold.log_vxy + ((size_t)env * 2 + half) * cap;
     double mn[kQualityDim], mx[kQualityDim], s1[kQualityDim], s2[kQualityDim];
 #pragma unroll
     for (int k = 0; k < kQualityDim; k++) { mn[k] = kInf; mx[k] = -kInf; s1[k] = 0; s2[k] = 0; }
@@ -131,7 +132,7 @@ k_element_quality(DevState S, int which, double *__restrict__ elem_out, double *
             const int kn = gid[k] & ~kNewBit;
             const bool created = (gid[k] & kNewBit) != 0;
             const double kNaN = __builtin_nan("");
-            const double2 v = created ? (kn < cap ? vnew[kn] : make_double2(kNaN, kNaN)) : S.dom_xy[doff + gid[k]];
+            const double2 v = created ? (kn < cap ? vnew[kn] : make_double2(kNaN, kNaN)) : cold.dom_xy[doff + gid[k]];
             m[k] = mkp(v.x, v.y);
         }
         double q[kQualityDim];

@@ -75,14 +75,29 @@ struct LastEpisode {
     int32_t episodes;         // episodes archived so far
 };
 
-struct DevState {
-    // ---- domain table
-    int n_domains;
-    DomConst *dom;            // [D]
+// Pointers only the rare paths need (reset, element / vertex logging, the quality report).  They live in device memory
+// behind DevState::cold and are fetched where they are used: as kernel arguments they would sit in -- or be spilled from --
+// the scalar registers of every wave of every step.
+struct DevCold {
     const double2 *dom_xy;    // [sum n0]
     double *dom_key;          // [sum n0] reset-time candidate keys
     int32_t *dom_stamp;       // [sum n0] -index, or kNotCand
     float *dom_obs;           // [D][18] first observation
+    // ---- logs (generated_meshes / boundary.vertices), optional
+    // Two halves per env: the running episode writes half (status >> 4) & 1; a reset that ends an episode with
+    // elements flips the bit, so the finished mesh (what the reference's eval callback reads from
+    // env.generated_meshes before it resets, CustomizeCallback.py:131-133) stays readable under auto-reset.
+    int32_t *log_quads;       // [E][2][log_cap][4]
+    double2 *log_vxy;         // [E][2][log_cap]
+    LastEpisode *last_ep;     // [E] extent of the archived half
+    int64_t pad;
+};
+
+struct DevState {
+    // ---- domain table
+    int n_domains;
+    DomConst *dom;            // [D]
+    const DevCold *cold;      // device copy of the rarely used pointers
     // ---- environments
     int n_envs;
     int cap;                  // ring stride
@@ -94,17 +109,19 @@ struct DevState {
     EnvCounters *cnt;         // [E]
     float *obs_cache;         // [E][18] observation of the current state
     float *msg;               // optional [E][21] packed (obs | reward | done | complete) float32 output, NULL = off
-    // ---- logs (generated_meshes / boundary.vertices), optional
-    // Two halves per env: the running episode writes half (status >> 4) & 1; a reset that ends an episode with
-    // elements flips the bit, so the finished mesh (what the reference's eval callback reads from
-    // env.generated_meshes before it resets, CustomizeCallback.py:131-133) stays readable under auto-reset.
-    int32_t *log_quads;       // [E][2][log_cap][4]
-    double2 *log_vxy;         // [E][2][log_cap]
-    LastEpisode *last_ep;     // [E] extent of the archived half
 #ifdef MESHENV_STAMPS
     unsigned long long *dbg;  // [E][16] diagnostic build: in-kernel timeline stamps
 #endif
     Params prm;
 };
+
+// The cold pointers, loaded at the point of use (the empty asm keeps the compiler from hoisting the loads into the
+// kernel prologue, where they would occupy scalar registers on every path).
+__device__ __forceinline__ DevCold load_cold(const DevState &S)
+{
+    const DevCold *p = S.cold;
+    asm volatile("" : "+s"(p));
+    return *p;
+}
 
 }  // namespace meshenv
