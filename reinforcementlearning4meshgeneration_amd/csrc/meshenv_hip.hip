@@ -355,15 +355,16 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
     if (n_steps == 1 && h->group > 1) {
         const int G = h->group;
         const dim3 grid((h->n_envs + G - 1) / G), block(64 * G);
-        if (G == 16)
-            hipLaunchKernelGGL((k_step_group<16, true>), grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
-                               reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
-        else if (G == 8)
-            hipLaunchKernelGGL((k_step_group<8, true>), grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
-                               reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
-        else
-            hipLaunchKernelGGL((k_step_group<4, true>), grid, block, h->group_lds, h->stream, h->S, h->cap, actions_dev, obs_dev,
-                               reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
+        GroupArgs A;
+        A.S = h->S;
+        A.outs.obs_out = obs_dev; A.outs.reward = reward_dev; A.outs.done = done_dev; A.outs.complete = complete_dev;
+        A.outs.term_obs = terminal_obs_dev;
+        A.actions = actions_dev;
+        A.cap = h->cap;
+        A.auto_reset = auto_reset;
+        if (G == 16) hipLaunchKernelGGL((k_step_group<16, true>), grid, block, h->group_lds, h->stream, A);
+        else if (G == 8) hipLaunchKernelGGL((k_step_group<8, true>), grid, block, h->group_lds, h->stream, A);
+        else hipLaunchKernelGGL((k_step_group<4, true>), grid, block, h->group_lds, h->stream, A);
     } else {
         const dim3 grid(h->n_envs), block(64);
 #define MESHENV_LAUNCH_STEP(MULTI, DEF)                                                                                      \

@@ -1254,14 +1254,54 @@ __host__ __device__ __forceinline__ size_t group_lds_bytes(int cap, int G)
     return (size_t)G * (lds_bytes_for(cap) + sizeof(Handoff));
 }
 
+// Where a step's results go.  In the CU-group kernel these five pointers are read from the kernel-argument segment at
+// the END of the step (late_outs): loaded at kernel entry they would be spilled and reloaded by every wave.
+struct StepOuts {
+    float *obs_out;
+    double *reward;
+    uint8_t *done;
+    uint8_t *complete;
+    float *term_obs;
+};
+
+// the single by-value argument of k_step_group: its layout IS the kernel-argument segment
+struct GroupArgs {
+    DevState S;
+    StepOuts outs;
+    const float *actions;
+    int cap;
+    int auto_reset;
+};
+
+__device__ __forceinline__ StepOuts late_outs()
+{
+    typedef const __attribute__((address_space(4))) char *kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));  // not before this point
+    typedef const __attribute__((address_space(4))) unsigned long long *qptr;
+    qptr q = (qptr)(ka + offsetof(GroupArgs, outs));
+    static_assert(sizeof(StepOuts) == 5 * sizeof(unsigned long long), "StepOuts is five pointers");
+    StepOuts o;
+    o.obs_out = (float *)q[0];
+    o.reward = (double *)q[1];
+    o.done = (uint8_t *)q[2];
+    o.complete = (uint8_t *)q[3];
+    o.term_obs = (float *)q[4];
+    return o;
+}
+
 // reward / flags / observation of one finished step, auto-reset, state write-back, work counters
 __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, const Decision &d, const EnvCounters &cnt0,
-                                                 int n_before, float *__restrict__ obs_out, double *__restrict__ reward,
-                                                 uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
-                                                 float *__restrict__ term_obs, int auto_reset)
+                                                 int n_before, int auto_reset)
 {
     const StepResult r = env_finish(c, S.prm, d);
     const int env = c.env;
+    const StepOuts o = late_outs();
+    float *__restrict__ obs_out = o.obs_out;
+    double *__restrict__ reward = o.reward;
+    uint8_t *__restrict__ done = o.done;
+    uint8_t *__restrict__ complete = o.complete;
+    float *__restrict__ term_obs = o.term_obs;
     if (c.lane == 0) {
         reward[env] = r.reward;
         done[env] = (uint8_t)r.done;
@@ -1297,11 +1337,12 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
 // ~40 scalars are handed over (Handoff).  Environments stay independent: no data is shared between envs.
 template <int G, bool kDefaultParams>
 __global__ void __launch_bounds__(64 * G)
-k_step_group(DevState S, int cap, const float *__restrict__ actions, float *__restrict__ obs_out,
-             double *__restrict__ reward, uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
-             float *__restrict__ term_obs, int auto_reset)
+k_step_group(GroupArgs A)
 {
     extern __shared__ double2 smem[];
+    DevState S = A.S;
+    const int cap = A.cap, auto_reset = A.auto_reset;
+    const float *__restrict__ actions = A.actions;
     if (kDefaultParams) apply_default_params(S.prm);
     const int wave = uniform_i32((int)(threadIdx.x >> 6));  // wave-uniform by construction: keeps env and every address derived from it in SGPRs
     const size_t env_bytes = lds_bytes_for(cap);
@@ -1324,7 +1365,7 @@ k_step_group(DevState S, int cap, const float *__restrict__ actions, float *__re
         const int n_before = c.n;
         Decision d = env_check(c, S, a0, a1, a2);
         if (!d.ok) {
-            finish_and_store(c, S, d, cnt0, n_before, obs_out, reward, done, complete, term_obs, auto_reset);
+            finish_and_store(c, S, d, cnt0, n_before, auto_reset);
         } else {
             pending = 1;
             if (c.lane == 0) {
@@ -1409,7 +1450,7 @@ k_step_group(DevState S, int cap, const float *__restrict__ actions, float *__re
 #ifdef MESHENV_STAMPS
     const unsigned long long dbg_t8 = __builtin_amdgcn_s_memrealtime();
 #endif
-    finish_and_store(c, S, d, cnt0, n_before, obs_out, reward, done, complete, term_obs, auto_reset);
+    finish_and_store(c, S, d, cnt0, n_before, auto_reset);
 #ifdef MESHENV_STAMPS
     if (c.lane == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
