@@ -29,6 +29,7 @@ struct MeshEnv {
     hipStream_t stream = nullptr;
     DevState S{};
     int n_envs = 0, n_domains = 0, cap = 0, max_ring = 0;
+    uint64_t steps_done = 0;  // vector steps executed so far (index of the next step)
     DevCold cold{};  // host copy of *S.cold
     bool default_params = true;  // geometry constants are the reference's: literal-constant kernel instantiations
     size_t lds = 0;
@@ -306,7 +307,7 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
 
     hipLaunchKernelGGL(k_init_domains, dim3(n_domains), dim3(64), lds, h->stream, S, cap);
     CREATE_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_reset, dim3(n_envs), dim3(64), lds, h->stream, S, cap, (const uint8_t *)nullptr, (float *)nullptr, 1);
+    hipLaunchKernelGGL(k_reset, dim3(n_envs), dim3(64), lds, h->stream, S, cap, (const uint8_t *)nullptr, (float *)nullptr, 1, 0ULL);
     CREATE_HIP(hipGetLastError());
     CREATE_HIP(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
@@ -338,7 +339,8 @@ int meshenv_group_size(const MeshEnv *h) { return h ? h->group : MESHENV_E_ARG; 
 int meshenv_reset(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev)
 {
     if (!h) return MESHENV_E_ARG;
-    hipLaunchKernelGGL(k_reset, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, mask_dev, obs_dev, 0);
+    hipLaunchKernelGGL(k_reset, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, mask_dev, obs_dev, 0,
+                       (unsigned long long)h->steps_done);
     HIP_TRY(h, hipGetLastError());
     return MESHENV_OK;
 }
@@ -360,6 +362,7 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         A.outs.obs_out = obs_dev; A.outs.reward = reward_dev; A.outs.done = done_dev; A.outs.complete = complete_dev;
         A.outs.term_obs = terminal_obs_dev;
         A.actions = actions_dev;
+        A.step0 = (unsigned long long)h->steps_done;
         A.cap = h->cap;
         A.auto_reset = auto_reset;
         if (G == 16) hipLaunchKernelGGL((k_step_group<16, true>), grid, block, h->group_lds, h->stream, A);
@@ -369,7 +372,7 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         const dim3 grid(h->n_envs), block(64);
 #define MESHENV_LAUNCH_STEP(MULTI, DEF)                                                                                      \
     hipLaunchKernelGGL((k_step<MULTI, DEF>), grid, block, h->lds, h->stream, h->S, h->cap, n_steps, actions_dev, obs_dev,   \
-                       reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset)
+                       reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset, (unsigned long long)h->steps_done)
         if (n_steps == 1) {
             if (h->default_params) MESHENV_LAUNCH_STEP(false, true);
             else MESHENV_LAUNCH_STEP(false, false);
@@ -380,6 +383,7 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
 #undef MESHENV_LAUNCH_STEP
     }
     HIP_TRY(h, hipGetLastError());
+    h->steps_done += (uint64_t)n_steps;
     if (pos >= 0 && pos == h->timing - 1) {
         HIP_TRY(h, hipEventRecord(h->ev[2 * slot + 1], h->stream));
         h->ev_count += 1;
@@ -546,12 +550,14 @@ int meshenv_counters(MeshEnv *h, uint64_t *out_host)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::vector<EnvCounters> c((size_t)h->n_envs);
+    std::vector<EnvScalars> sc((size_t)h->n_envs);
     HIP_TRY(h, hipMemcpy(c.data(), h->S.cnt, sizeof(EnvCounters) * (size_t)h->n_envs, hipMemcpyDeviceToHost));
-    uint64_t a = 0, b = 0, s = 0, sv = 0;
-    for (const EnvCounters &k : c) {
-        a += k.steps;
+    HIP_TRY(h, hipMemcpy(sc.data(), h->S.scal, sizeof(EnvScalars) * (size_t)h->n_envs, hipMemcpyDeviceToHost));
+    uint64_t a = h->steps_done * (uint64_t)h->n_envs, b = 0, s = 0, sv = 0;
+    for (int e = 0; e < h->n_envs; e++) {
+        const EnvCounters &k = c[(size_t)e];
         b += k.valid;
-        s += k.sum_n;
+        s += k.sum_n + (uint64_t)sc[(size_t)e].n * (h->steps_done - k.last_change);  // the running term of the lazy sum
         sv += k.sum_n_valid;
     }
     out_host[0] = a;

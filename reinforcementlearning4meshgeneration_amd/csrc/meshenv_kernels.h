@@ -167,11 +167,16 @@ __device__ __forceinline__ void store_env(Ctx &c, const DevState &S)
         if (c.lane < kObsDim) S.obs_cache[(size_t)c.env * kObsDim + c.lane] = c.obs;
     }
     if (c.lane == 0) {
-        EnvScalars s;
-        s.n = c.n; s.ref = c.ref; s.n_elem = c.n_elem; s.failed = c.failed; s.n_new = c.n_new;
-        s.counter = c.counter; s.status = c.status; s.dom = c.dom; s.bl = c.bl; s.area = c.area;
-        s.ct = c.ct; s.st = c.st;
-        S.scal[c.env] = s;
+        if (c.ring_dirty) {
+            EnvScalars s;
+            s.n = c.n; s.ref = c.ref; s.n_elem = c.n_elem; s.failed = c.failed; s.n_new = c.n_new;
+            s.counter = c.counter; s.status = c.status; s.dom = c.dom; s.bl = c.bl; s.area = c.area;
+            s.ct = c.ct; s.st = c.st;
+            S.scal[c.env] = s;
+        } else {  // a rejected action: only failed_num and the status bits moved
+            int2 *fs = reinterpret_cast<int2 *>(&S.scal[c.env].failed);
+            *fs = make_int2(c.failed, c.status);
+        }
     }
 }
 
@@ -1119,7 +1124,8 @@ __global__ void __launch_bounds__(64) k_init_domains(DevState S, int cap)
     }
 }
 
-__global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t *mask, float *obs_out, int first)
+__global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t *mask, float *obs_out, int first,
+                                               unsigned long long step_now)
 {
     extern __shared__ double2 smem[];
     Ctx c;
@@ -1142,10 +1148,17 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
         c.n_new = uniform_i32(S.scal[env].n_new);
         c.status = uniform_i32(S.scal[env].status);
     }
+    const int n_old = c.n;
     reset_from_domain(c, S);
-    if (first && c.lane == 0) {
+    if (c.lane == 0) {
         EnvCounters z;
-        z.steps = 0; z.valid = 0; z.sum_n = 0; z.sum_n_valid = 0;
+        if (first) {
+            z.last_change = 0; z.valid = 0; z.sum_n = 0; z.sum_n_valid = 0;
+        } else {  // the ring length changes here: close the running term of sum_n
+            z = S.cnt[env];
+            z.sum_n += (unsigned long long)n_old * (step_now - z.last_change);
+            z.last_change = step_now;
+        }
         S.cnt[env] = z;
     }
     store_env(c, S);
@@ -1163,7 +1176,7 @@ template <bool kMulti, bool kDefaultParams>
 __global__ void __launch_bounds__(64, MESHENV_STEP_WAVES_PER_SIMD)
 k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, float *__restrict__ obs_out,
        double *__restrict__ reward, uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
-       float *__restrict__ term_obs, int auto_reset)
+       float *__restrict__ term_obs, int auto_reset, unsigned long long step0)
 {
     extern __shared__ double2 smem[];
     if (kDefaultParams) apply_default_params(S.prm);
@@ -1186,7 +1199,12 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     if (c.lane < 16) c.sc->stamps[c.lane] = 0;
     wave_sync();
 #endif
-    unsigned long long st_valid = 0, st_sum = 0, st_sumv = 0;
+#ifdef MESHENV_STAMPS
+    unsigned long long st_valid = 0;
+#else
+    EnvCounters k = cnt0;
+    bool k_dirty = false;
+#endif
     double last_reward = 0.0;
     int last_done = 0, last_complete = 0;
     const int T = kMulti ? n_steps : 1;
@@ -1197,8 +1215,17 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
         }
         const int n_before = c.n;
         const StepResult r = env_step(c, S, a0, a1, a2);
-        st_sum += (unsigned long long)n_before;
-        if (r.valid) { st_valid += 1; st_sumv += (unsigned long long)n_before; }
+#ifdef MESHENV_STAMPS
+        if (r.valid) st_valid += 1;
+#else
+        if (r.valid || (r.done && auto_reset)) {  // the ring length changes after this step: close the running term
+            const unsigned long long next = step0 + (unsigned long long)t + 1ULL;
+            k.sum_n += (unsigned long long)n_before * (next - k.last_change);
+            k.last_change = next;
+            if (r.valid) { k.valid += 1ULL; k.sum_n_valid += (unsigned long long)n_before; }
+            k_dirty = true;
+        }
+#endif
         const size_t o = (size_t)t * E + env;
         if (c.lane == 0) {
             reward[o] = r.reward;
@@ -1221,7 +1248,7 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     // diagnostic build only: per-wave timeline (100 MHz realtime ticks) instead of the work counters
     if (c.lane == 0) {
         EnvCounters k;
-        k.steps = stamp_t0; k.valid = stamp_t1; k.sum_n = __builtin_amdgcn_s_memrealtime();
+        k.last_change = stamp_t0; k.valid = stamp_t1; k.sum_n = __builtin_amdgcn_s_memrealtime();
         k.sum_n_valid = st_valid | ((unsigned long long)(a0 <= -0.5f ? 1 : (a0 >= 0.5f ? 2 : 0)) << 8);
         S.cnt[env] = k;
     }
@@ -1229,11 +1256,7 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     wave_sync();
     if (c.lane < 16) S.dbg[(size_t)env * 16 + c.lane] = c.sc->stamps[c.lane];
 #else
-    if (c.lane == 0) {
-        EnvCounters k = cnt0;
-        k.steps += (unsigned long long)T; k.valid += st_valid; k.sum_n += st_sum; k.sum_n_valid += st_sumv;
-        S.cnt[env] = k;
-    }
+    if (k_dirty && c.lane == 0) S.cnt[env] = k;
 #endif
 }
 
@@ -1269,6 +1292,7 @@ struct GroupArgs {
     DevState S;
     StepOuts outs;
     const float *actions;
+    unsigned long long step0;  // index of this step since the handle was created (lazy work counters)
     int cap;
     int auto_reset;
 };
@@ -1292,7 +1316,7 @@ __device__ __forceinline__ StepOuts late_outs()
 
 // reward / flags / observation of one finished step, auto-reset, state write-back, work counters
 __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, const Decision &d, const EnvCounters &cnt0,
-                                                 int n_before, int auto_reset)
+                                                 int n_before, int auto_reset, unsigned long long step0)
 {
     const StepResult r = env_finish(c, S.prm, d);
     const int env = c.env;
@@ -1317,10 +1341,10 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
         S.msg[(size_t)env * 21 + c.lane] = v;
     }
     store_env(c, S);
-    if (c.lane == 0) {
+    if ((r.valid || (r.done && auto_reset)) && c.lane == 0) {  // the ring length changes after this step
         EnvCounters k = cnt0;
-        k.steps += 1ULL;
-        k.sum_n += (unsigned long long)n_before;
+        k.sum_n += (unsigned long long)n_before * (step0 + 1ULL - k.last_change);
+        k.last_change = step0 + 1ULL;
         if (r.valid) { k.valid += 1ULL; k.sum_n_valid += (unsigned long long)n_before; }
         S.cnt[env] = k;
     }
@@ -1365,7 +1389,7 @@ k_step_group(GroupArgs A)
         const int n_before = c.n;
         Decision d = env_check(c, S, a0, a1, a2);
         if (!d.ok) {
-            finish_and_store(c, S, d, cnt0, n_before, auto_reset);
+            finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0);
         } else {
             pending = 1;
             if (c.lane == 0) {
@@ -1450,7 +1474,7 @@ k_step_group(GroupArgs A)
 #ifdef MESHENV_STAMPS
     const unsigned long long dbg_t8 = __builtin_amdgcn_s_memrealtime();
 #endif
-    finish_and_store(c, S, d, cnt0, n_before, auto_reset);
+    finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0);
 #ifdef MESHENV_STAMPS
     if (c.lane == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();

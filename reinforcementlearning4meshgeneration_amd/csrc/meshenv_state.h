@@ -22,18 +22,23 @@ struct alignas(64) EnvScalars {
     int32_t n;         // len(updated_boundary.vertices)
     int32_t ref;       // ring index of current_point_environment.reference_point (-1: None)
     int32_t n_elem;    // len(generated_meshes)
-    int32_t failed;    // failed_num
     int32_t n_new;     // new vertices appended to boundary.vertices this episode
     int32_t counter;   // candidate insertion stamp counter
-    int32_t status;    // MESHENV_ST_* bits
     int32_t dom;       // domain index
+    // the two fields a rejected action changes, adjacent: such a step writes these 8 bytes, not the record
+    int32_t failed;    // failed_num
+    int32_t status;    // MESHENV_ST_* bits
     double bl;         // current_point_environment.base_length
     double area;       // current_area
     double ct, st;     // cos / sin of the action frame angle 2*pi - atan2(right - ref) (D:69-73), per state
 };
 
+// Work counters of one env (roofline accounting).  The ring length n only changes on a valid extraction or a reset, so
+// the sum of n over steps is kept lazily: sum_n covers the steps before last_change, the host adds
+// n_current * (steps_done - last_change).  Rejected actions (88 % of the steps) do not touch the record.
 struct alignas(32) EnvCounters {
-    unsigned long long steps, valid, sum_n, sum_n_valid;
+    unsigned long long last_change;  // index of the first step the current ring length applies to
+    unsigned long long valid, sum_n, sum_n_valid;
 };
 
 // per-domain constants + the scalars reset() derives

@@ -107,7 +107,10 @@ def _run_lockstep(torch, domains, env_domain, actions, check_every=64, sample=64
         _, rew_all, done_all, comp_all = env.rollout(acts_dev)
         rew_all = rew_all.cpu().numpy(); done_all = done_all.cpu().numpy(); comp_all = comp_all.cpu().numpy()
     rng = np.random.default_rng(0)
+    sum_ring = 0
     for t in range(T):
+        if n <= 512:   # the lazily kept sum of ring lengths over all steps (roofline accounting) against the oracle
+            sum_ring += sum(r.L.meshenv_ref_ring_len(r.h) for r in refs)
         o_ref, r_ref, d_ref, c_ref = batch.step(actions[t], auto_reset=True, threads=8)
         if rollout:
             r, d, c = rew_all[t], done_all[t], comp_all[t]
@@ -142,6 +145,8 @@ def _run_lockstep(torch, domains, env_domain, actions, check_every=64, sample=64
     cnt = env.counters()
     stats["valid"] = cnt["valid"]
     assert cnt["steps"] == T * n
+    if n <= 512:
+        assert cnt["sum_ring"] == sum_ring, (cnt, sum_ring)
     env.close()
     return stats
 
