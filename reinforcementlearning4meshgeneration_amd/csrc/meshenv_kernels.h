@@ -1419,24 +1419,22 @@ k_step_group(GroupArgs A)
     }
 #endif
 
-    // ---- deal the pending updates over the SIMDs
-    unsigned vmask = 0, smask[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int w = 0; w < G; w++) {
-        const int v = ho[w].valid, sd = ho[w].simd & 3;
-        vmask |= (unsigned)(v != 0) << w;
-        smask[0] |= (unsigned)(sd == 0) << w;
-        smask[1] |= (unsigned)(sd == 1) << w;
-        smask[2] |= (unsigned)(sd == 2) << w;
-        smask[3] |= (unsigned)(sd == 3) << w;
+    // ---- deal the pending updates over the SIMDs (lane w reads wave w's entry: five ballots, not a 16-step loop)
+    const int dl = threadIdx.x & 63;
+    int hv = 0, hs = -1;
+    if (dl < G) {
+        hv = ho[dl].valid;
+        hs = ho[dl].simd & 3;
     }
-    vmask = (unsigned)uniform_i32((int)vmask);
+    const unsigned vmask = (unsigned)__ballot(hv != 0);
     const int m = __popc(vmask);
     if (m == 0) return;
-    const int my_simd = uniform_i32(ho[wave].simd & 3);
-    const unsigned mine = (unsigned)uniform_i32((int)(my_simd == 0 ? smask[0] : my_simd == 1 ? smask[1] : my_simd == 2 ? smask[2] : smask[3]));
-    const bool balanced = __popc((unsigned)uniform_i32((int)smask[0])) * 4 == G && __popc((unsigned)uniform_i32((int)smask[1])) * 4 == G &&
-                          __popc((unsigned)uniform_i32((int)smask[2])) * 4 == G && __popc((unsigned)uniform_i32((int)smask[3])) * 4 == G;
+    const unsigned sm0 = (unsigned)__ballot(hs == 0), sm1 = (unsigned)__ballot(hs == 1);
+    const unsigned sm2 = (unsigned)__ballot(hs == 2), sm3 = (unsigned)__ballot(hs == 3);
+    const unsigned wbit = 1u << wave;
+    const int my_simd = (sm1 & wbit) ? 1 : (sm2 & wbit) ? 2 : (sm3 & wbit) ? 3 : 0;
+    const unsigned mine = my_simd == 0 ? sm0 : my_simd == 1 ? sm1 : my_simd == 2 ? sm2 : sm3;
+    const bool balanced = __popc(sm0) * 4 == G && __popc(sm1) * 4 == G && __popc(sm2) * 4 == G && __popc(sm3) * 4 == G;
     int src = -1;
     if (balanced && G >= 4) {
         const int j = __popc(mine & ((1u << wave) - 1u)) * 4 + my_simd;  // my turn in the deal
