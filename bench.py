@@ -102,7 +102,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-process flow on a one-GPU box together with MESHENV_BENCH_DEVICE=0)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--time-every", type=int, default=8, help="HIP-event-time every k-th launch of the timed region")
+    ap.add_argument("--time-every", type=int, default=25,
+                    help="HIP events bracket every other group of k consecutive launches of the timed region (an event pair costs ~8 us of stream time, so k is kept large)")
     args = ap.parse_args()
 
     import torch
@@ -243,7 +244,7 @@ def main():
         traffic, traffic_src = pmc_traffic(n)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                           "kernel": ("meshenv::k_step_group<%d>" % env.group_size) if env.group_size > 1 else "meshenv::k_step<false>",
+                           "kernel": ("meshenv::k_step_group<%d, true>" % env.group_size) if env.group_size > 1 else "meshenv::k_step<false, true>",
                            "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": float(np.min(kt)) * 1e3,
                            "algorithmic_bytes_per_launch": alg, "launches_timed": int(len(kt)) * args.time_every,
                            "timing": "HIP events on the launch stream bracketing groups of %d consecutive launches" % args.time_every}
