@@ -129,8 +129,9 @@ __device__ __forceinline__ double cw(P2 s, P2 p1, P2 p2)
 //    never zero.  (Every non-degenerate configuration ends here: two cross products, no transcendental.)
 //  * otherwise r = c/d, |r| <= 1e-3 and atan(r) = r to within 3.4e-10, so the angle is known to 3.4e-10 and each of
 //    the four sign cases below reduces "a in {0, 3.1416, 6.2832}" to one comparison of |r| against the matching
-//    rounding boundary.  Within 1e-8 of a boundary (and for d == 0, which implies c == 0) the reference
-//    evaluation (atan2, round, sin, round) is used, so the result is the reference's in every case.
+//    rounding boundary -- done as |c| against boundary * |d|, no division.  Within 1e-8 of a boundary (and for
+//    d == 0, which implies c == 0) the reference evaluation (atan2, round, sin, round) is used, so the result is the
+//    reference's in every case.
 // (out of line: the rare guard-band / degenerate path; keeping it out of straddle() leaves straddle a leaf that
 // inlines into the kernels -- as a non-leaf function it saved its return address through a scratch-memory spill,
 // a full memory round trip per call)
@@ -144,18 +145,20 @@ __device__ __forceinline__ bool sin_rounds_to_zero(double c, double d)
 #ifdef MESHENV_NO_FILTERS
     return sin_rounds_to_zero_exact(c, d);
 #else
-    if (fabs(c) > 1e-3 * fabs(d)) return false;
+    const double ac = fabs(c), ad = fabs(d);
+    if (ac > 1e-3 * ad) return false;
     if (d != 0.0) {
-        const double r = c / d;
-        double x, thr;
-        if (d > 0.0) {
-            if (signbit(c)) { x = -r; thr = 5e-5; }                      // theta = -t >= +0: a = round(theta) == 0.0
-            else { x = r; thr = 2 * kPi - 6.28315; }                     // theta < 0: a = round(2pi + theta) == 6.2832
-        } else {
-            if (!signbit(c)) { x = -r; thr = 3.14165 - kPi; }            // t = pi + r: a = round(pi + |r|) == 3.1416
-            else { x = r; thr = kPi - 3.14155; }                         // t = -pi + r: a = round(pi - r) == 3.1416
-        }
-        if (fabs(x - thr) > 1e-8) return x < thr;
+        // In all four sign cases the quantity compared with its boundary is |c / d|:
+        //   d > 0, c < 0 (or -0): theta = -t >= +0, a = round(theta) == 0.0            <=>  |r| < 5e-5
+        //   d > 0, c >= +0:       theta < 0, a = round(2pi + theta) == 6.2832          <=>  |r| < 2pi - 6.28315
+        //   d < 0, c >= +0:       t = pi - |r|, a = round(pi + |r|) == 3.1416          <=>  |r| < 3.14165 - pi
+        //   d < 0, c < 0:         t = -pi + |r|, a = round(pi - |r|) == 3.1416         <=>  |r| < pi - 3.14155
+        // compared without the division: |c| against thr * |d|, guard band 1e-8 * |d| (the products round to ~1e-16
+        // relative, far inside the band)
+        const bool cneg = signbit(c), dpos = d > 0.0;
+        const double thr = dpos ? (cneg ? 5e-5 : 2 * kPi - 6.28315) : (cneg ? kPi - 3.14155 : 3.14165 - kPi);
+        const double rhs = thr * ad;
+        if (fabs(ac - rhs) > 1e-8 * ad) return ac < rhs;
     }
     return sin_rounds_to_zero_exact(c, d);
 #endif
