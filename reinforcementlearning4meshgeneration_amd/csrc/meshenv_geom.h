@@ -90,11 +90,28 @@ __device__ MESHENV_NOINLINE double sin_nc(double a) { return sin(a); }
 
 // ---------------------------------------------------------------------------------- primitives
 // Point2D.distance_to, C:17-18.  (The reference's `** 2` is libm pow(x, 2.0), which differs from x*x by
+// IEEE-correct square root for arguments that are zero or lie in [2^-767, 2^1023): the compiler's own expansion of
+// sqrt(double) (v_rsq_f64 seed, two coupled Newton steps, two residual corrections) without its range scaling -- the
+// ldexp by 2^+-256 / 2^-+128 and the compare that decide it are 6 of its ~19 instructions, and sums of squared
+// coordinate differences are never subnormal-small.  Bit-identical to sqrt() on that range (tests/test_gpu_primitives.py).
+__device__ __forceinline__ double sqrt_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double s0 = x * y, h0 = 0.5 * y;
+    const double r0 = fma(-h0, s0, 0.5);
+    const double h1 = fma(h0, r0, h0), s1 = fma(s0, r0, s0);
+    const double d0 = fma(-s1, s1, x);
+    const double s2 = fma(d0, h1, s1);
+    const double d1 = fma(-s2, s2, x);
+    const double r = fma(d1, h1, s2);
+    return (x == 0.0 || x == __builtin_huge_val()) ? x : r;  // rsq(0) = inf, rsq(inf) = 0: both would give NaN
+}
+
 // one ulp for 0.085 % of doubles; the device uses the exactly rounded product -- see DESIGN.md.)
 __device__ __forceinline__ double dist(P2 a, P2 b)
 {
     const double dx = a.x - b.x, dy = a.y - b.y;
-    return sqrt(dx * dx + dy * dy);
+    return sqrt_pos(dx * dx + dy * dy);
 }
 
 // numerator / denominator of the clockwise angle: cross(v1,v2), dot(v1,v2) with v1 = p1-s, v2 = p2-s

@@ -599,6 +599,7 @@ __global__ void k_selftest(int what, int n, const double *in, double *out)
     else if (what == 4) out[i] = (sin_rounds_to_zero(in[2 * i], in[2 * i + 1]) ? 1.0 : 0.0) + (sin_rounds_to_zero_exact(in[2 * i], in[2 * i + 1]) ? 2.0 : 0.0);
     else if (what == 5) out[i] = (double)round4_npf((float)in[i]);
     else if (what == 6) out[i] = dist(mkp(in[4 * i], in[4 * i + 1]), mkp(in[4 * i + 2], in[4 * i + 3]));
+    else if (what == 7) out[i] = (sqrt_pos(in[i]) == sqrt(in[i])) ? 1.0 : 0.0;  // against the compiler's IEEE sqrt
 }
 
 int meshenv_selftest(int device, int what, int n, int in_per_item, const double *in_host, double *out_host)

@@ -94,3 +94,17 @@ def test_distance_within_one_ulp_of_oracle():
     ulp = np.spacing(ref)
     assert np.all(np.abs(got - ref) <= ulp)
     assert (got != ref).mean() < 0.01
+
+
+def test_trimmed_sqrt_is_the_ieee_sqrt():
+    """sqrt_pos (the compiler's sqrt expansion without range scaling) equals sqrt() bit for bit on zero and on
+    [1e-200, 1e300] -- in particular on every sum of squared coordinate differences the kernels form."""
+    rng = np.random.default_rng(5)
+    p = np.round(rng.uniform(-50, 50, (300000, 4)), 4)
+    d2 = (p[:, 0] - p[:, 2]) ** 2 + (p[:, 1] - p[:, 3]) ** 2
+    x = np.concatenate([d2, 10.0 ** rng.uniform(-200, 300, 300000), rng.uniform(0, 4, 300000),
+                        np.array([0.0, 1.0, 2.0, 4.0, 1e-8, 2.5e-9, np.nextafter(1.0, 2), np.nextafter(1.0, 0), 1e-200, 1e300])])
+    k = rng.integers(1, 2 ** 26, 200000).astype(np.float64)
+    x = np.concatenate([x, k * k, np.nextafter(k * k, 0), np.nextafter(k * k, np.inf)])   # exact squares and neighbours
+    got = _run(7, x)
+    assert np.all(got == 1.0), np.flatnonzero(got != 1.0)[:10]
