@@ -315,6 +315,18 @@ __device__ __forceinline__ double wave_min_f64(double v)
     return lane_f64(v, 63);
 }
 
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#define STEP(CTRL, MASK)                                                  \
+    {                                                                     \
+        const int ov = dpp_i32<CTRL, MASK>((int)0x80000000, v);           \
+        v = ov > v ? ov : v;                                              \
+    }
+    MESHENV_DPP_REDUCE(STEP)
+#undef STEP
+    return lane_i32(v, 63);
+}
+
 typedef unsigned long long u64;
 
 template <int kCtrl, int kRowMask>

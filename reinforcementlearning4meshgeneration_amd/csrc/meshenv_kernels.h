@@ -194,16 +194,13 @@ __device__ __forceinline__ int select_reference(const Ctx &c)
             if (k < bk || (k == bk && st > bs)) { bk = k; bs = st; bi = i; }
         }
     }
-#define STEP(CTRL, MASK)                                                        \
-    {                                                                           \
-        const double ok = dpp_f64<CTRL, MASK>(kInf, bk);                        \
-        const int os = dpp_i32<CTRL, MASK>(kNotCand, bs);                       \
-        const int oi = dpp_i32<CTRL, MASK>(-1, bi);                             \
-        if (ok < bk || (ok == bk && os > bs)) { bk = ok; bs = os; bi = oi; }    \
-    }
-    MESHENV_DPP_REDUCE(STEP)
-#undef STEP
-    return lane_i32(bi, 63);
+    // (key asc, stamp desc): stamps are unique among candidates, so the winner is found in two plain reductions --
+    // the smallest key, then the largest stamp among the lanes that hold it -- and located with one ballot
+    const double kmin = wave_min_f64(bk);
+    if (!(kmin < kInf)) return -1;
+    const int smax = wave_max_i32(bk == kmin ? bs : kNotCand);
+    const unsigned long long hit = __ballot(bk == kmin && bs == smax);
+    return lane_i32(bi, (int)__ffsll((long long)hit) - 1);
 }
 
 // the two angles of MeshGeneration.check_boundary_point (M:202-231) for ring slot `index`:
