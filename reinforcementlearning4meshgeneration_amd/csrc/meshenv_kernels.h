@@ -1206,6 +1206,11 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     int last_done = 0, last_complete = 0;
     const int T = kMulti ? n_steps : 1;
     for (int t = 0; t < T; t++) {
+        if (kMulti) {
+            // the lane id is made opaque once per iteration: everything derived from it (predicates, select tables) is
+            // then recomputed inside the step instead of being hoisted out of the loop and spilled
+            asm volatile("" : "+v"(c.lane));
+        }
         if (kMulti && t > 0) {
             const float *at = actions + ((size_t)t * E + env) * 3;
             a0 = at[0]; a1 = at[1]; a2 = at[2];
