@@ -120,14 +120,23 @@ __device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env)
     const double *gkey = S.ring_key + c.base;
     const int32_t *gst = S.ring_stamp + c.base;
     const unsigned ul = (unsigned)lane;
-    double2 v_xy = make_double2(0, 0);
-    double v_key = 0;
-    int v_id = 0, v_st = kNotCand;
+    double2 v_xy = make_double2(0, 0), w_xy = make_double2(0, 0);
+    double v_key = 0, w_key = 0;
+    int v_id = 0, v_st = kNotCand, w_id = 0, w_st = kNotCand;
     if (lane < first) {
         v_xy = gxy[ul];
         v_id = gid[ul];
         v_key = gkey[ul];
         v_st = gst[ul];
+    }
+    // rings longer than 64: the second chunk is requested in the same burst, up to the ring STRIDE (known from the
+    // kernel arguments) rather than the ring length (known only once the record has arrived) -- no second round trip
+    const bool second = S.cap > 64 && (int)(64u + ul) < S.cap;
+    if (second) {
+        w_xy = gxy[64u + ul];
+        w_id = gid[64u + ul];
+        w_key = gkey[64u + ul];
+        w_st = gst[64u + ul];
     }
     c.obs = lane < kObsDim ? S.obs_cache[(size_t)env * kObsDim + lane] : 0.0f;
     c.n = uniform_i32(s.n); c.ref = uniform_i32(s.ref); c.n_elem = uniform_i32(s.n_elem);
@@ -141,7 +150,13 @@ __device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env)
         c.key[lane] = v_key;
         c.stamp[lane] = v_st;
     }
-    for (unsigned i = 64u + ul; i < (unsigned)c.n; i += 64u) {
+    if (second) {
+        c.xy[64u + ul] = w_xy;
+        c.id[64u + ul] = w_id;
+        c.key[64u + ul] = w_key;
+        c.stamp[64u + ul] = w_st;
+    }
+    for (unsigned i = 128u + ul; i < (unsigned)c.n; i += 64u) {
         c.xy[i] = gxy[i];
         c.id[i] = gid[i];
         c.key[i] = gkey[i];
