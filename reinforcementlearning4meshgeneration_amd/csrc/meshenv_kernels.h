@@ -377,22 +377,21 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     const int bqi = bq.a;
     const int w1 = wrapi(bqi + 1, n), w2 = wrapi(bqi + 2, n), w3 = wrapi(bqi - 1, n), w4 = wrapi(bqi - 2, n);
     const P2 add_v = ldp(c, bq.mode == 1 ? bqi : 0);
+    // traversal positions stage A had no lane for (rings longer than 58): their clockwise angles in full 64-lane
+    // passes of their own, so that a 120-vertex ring costs one more transcendental pass, not two
+    for (int o = kScanLanes + lane; o < n - 1; o += 64) {
+        double cc, dd;
+        cw_terms(ref, ldp(c, wrapi(idc - 1 - o, n)), right, cc, dd);
+        c.ang_ord[o] = cw_finish(atan2_nc(cc, dd));
+    }
+    wave_sync();
     for (int base = 0; base < n; base += 64) {
         // (1) observation scan
         const int ord = base + lane;
         const bool in_range = ord < n - 1;
         const int ii = wrapi(idc - 1 - (in_range ? ord : 0), n);
         const P2 v = ldp(c, ii);
-        const bool calc = in_range && ord >= kScanLanes;  // positions stage A had no lane for
-        double t = 0.0;
-        if (calc) {
-            double cc, dd;
-            cw_terms(ref, v, right, cc, dd);
-            t = atan2_nc(cc, dd);
-        }
-        double angle = cw_finish(t);
-        if (calc) c.ang_ord[ord] = angle;
-        else if (in_range) angle = c.ang_ord[ord];
+        const double angle = in_range ? c.ang_ord[ord] : 0.0;
         // (2) boundary-quality scan (mode 1): added(i) = near(i) && !added(i-1), M:355-357
         if (bq.mode == 1) {
             const int i = base + lane;
