@@ -625,19 +625,25 @@ __device__ __forceinline__ P2 vr_at(const Ctx &c, const VRing &r, int j)
 // pk = packed ring slots of ref_neighbors (4 x 16 bit... passed as four ints), bc0/bc1 = centres of the
 // boundary-quality angles on the post-update ring.
 __device__ __forceinline__ bool quad_pass(Ctx &c, const Params &prm, const VRing &vr, int p0, int p1, int p2, int p3,
-                                          int bc0, int bc1)
+                                          int bc0, int bc1, bool have_pre, double pre_qy, double pre_qx)
 {
     const int lane = c.lane;
     const double2 *q = c.sc->q;
     // (0) exact early reject.  Corner angle a = cw(m_i; m_i+1, m_i-1) with atan2 terms (cc, dd): cc > 0 gives
     //     theta = -atan2 < 0 -> a = round(2pi + theta) >= pi; cc == +-0 gives a in {0, pi, 2pi} (all rounded): every
     //     case violates 0.01pi <= a <= 0.99pi, so only cc < 0 can pass Mesh.is_valid -- no atan2 needed to fail.
+    //     (have_pre: env_check already evaluated -- and passed -- this test for the new-vertex quad; its terms are reused)
     double qy = -1.0, qx = 1.0;
-    if (lane < 4) {
-        const double2 a = q[lane], b = q[(lane + 1) & 3], d = q[(lane + 3) & 3];
-        cw_terms(mkp(a.x, a.y), mkp(b.x, b.y), mkp(d.x, d.y), qy, qx);
+    if (have_pre) {
+        qy = lane < 4 ? pre_qy : qy;
+        qx = lane < 4 ? pre_qx : qx;
+    } else {
+        if (lane < 4) {
+            const double2 a = q[lane], b = q[(lane + 1) & 3], d = q[(lane + 3) & 3];
+            cw_terms(mkp(a.x, a.y), mkp(b.x, b.y), mkp(d.x, d.y), qy, qx);
+        }
+        if (__ballot(!(qy < 0.0)) != 0ULL && prm.min_degree > 0.0 && prm.max_degree < kPi) return false;
     }
-    if (__ballot(!(qy < 0.0)) != 0ULL && prm.min_degree > 0.0 && prm.max_degree < kPi) return false;
     // (a) segments_crossed: is_cross(m0m1, m2m3) || is_cross(m0m3, m1m2); 4 independent straddles
     bool sres = false;
     if (lane < 4) {
@@ -805,7 +811,8 @@ struct Decision {
 // Checks of step(action), B:113-191: action decode, rule selection, point-in-polygon / same-point, quad validity,
 // boundary intersection.  a0 = rule type, (a1, a2) = candidate point in the local frame.  On success the quad,
 // its corner angles / edge lengths and the speculative candidate-key and boundary-quality angles are in c.sc.
-__device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a0, float a1, float a2)
+// (pre_reject: evaluate the quad's corner test before the point-in-polygon pass; a compile-time constant at each call)
+__device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a0, float a1, float a2, const bool pre_reject)
 {
     const Params &prm = S.prm;
     const int lane = c.lane;
@@ -831,7 +838,8 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
         return d;
     }
     int mp0, mp1, mp2, mp3, r;
-    bool new_vertex = false, have_filter = false;
+    bool new_vertex = false, have_filter = false, have_pre = false;
+    double pre_qy = 0.0, pre_qx = 0.0;
     int near_count = 0;
     P2 new_point = mkp(0.0, 0.0);
     int rule;
@@ -851,6 +859,49 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
         oy += p0.y;
         new_point = mkp(uniform_f64(round4_np(ox)), uniform_f64(round4_np(oy)));
         MESHENV_STAMP(c, 1);
+        // Exact early rejection before the point-in-polygon pass.  Unless the point coincides with a ring vertex
+        // (find_same_point, checked conservatively on squared distances), the only quad this action can build is
+        // [new, i-1, i, i+1]; if one of its corners has a non-negative cross term its angle cannot lie in
+        // [0.01 pi, 0.99 pi] (see quad_pass) and the step fails whether or not the point is inside -- with the same
+        // reward.  Four of five uniform-random rule-0 actions end here, ~30 instructions in.  Used by the rollout kernel
+        // only (+7 %): one step per launch gains nothing in the latency regime (the slowest chains are valid steps,
+        // which only pay for the test) and loses 4 % at 65 536 envs (measured, tools/ab_all.sh).
+        if (pre_reject && prm.min_degree > 0.0 && prm.max_degree < kPi) {
+            // the quad goes to the scratch slots quad_pass reads; lane k evaluates corner k: (self, next, previous)
+            wave_sync();
+            if (lane < 4) {
+                const int mp = lane == 1 ? wrapi(index - 1, n) : lane == 2 ? index : wrapi(index + 1, n);
+                c.sc->q[lane] = lane == 0 ? make_double2(new_point.x, new_point.y) : c.xy[mp];
+            }
+            wave_sync();
+            double qy = -1.0, qx = 1.0;
+            if (lane < 4) {
+                const double2 *q = c.sc->q;
+                const double2 a = q[lane], b = q[(lane + 1) & 3], dd = q[(lane + 3) & 3];
+                cw_terms(mkp(a.x, a.y), mkp(b.x, b.y), mkp(dd.x, dd.y), qy, qx);
+            }
+            pre_qy = qy; pre_qx = qx;
+            have_pre = true;
+            if (__ballot(lane < 4 && !(qy < 0.0)) != 0ULL) {  // the new-vertex quad is invalid; is it the quad at all?
+                have_pre = false;
+                const double eps2 = prm.same_eps * prm.same_eps * 1.000001;
+                bool maybe_same = false;
+                for (int base = 0; base < n; base += 64) {
+                    const int i = base + lane;
+                    bool near = false;
+                    if (i < n) {
+                        const P2 v = ldp(c, i);
+                        const double dx = v.x - new_point.x, dy = v.y - new_point.y;
+                        near = dx * dx + dy * dy < eps2;
+                    }
+                    maybe_same = maybe_same || (__ballot(near) != 0ULL);
+                }
+                if (!maybe_same) {
+                    d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;
+                    return d;
+                }
+            }
+        }
         const bool inside = point_inside(c, prm, new_point);
         MESHENV_STAMP(c, 2);
         if (!inside) {
@@ -897,14 +948,16 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
         p0 = wrapi(id, nn); p1 = wrapi(id - 1, nn); p2 = wrapi(id + 1, nn); p3 = wrapi(id - 2, nn);
         bc0 = t0; bc1 = t1;
     }
-    wave_sync();
-    if (lane < 4) {
-        const int mp = lane == 0 ? mp0 : lane == 1 ? mp1 : lane == 2 ? mp2 : mp3;
-        c.sc->q[lane] = mp < 0 ? make_double2(new_point.x, new_point.y) : c.xy[mp];
+    if (!(have_pre && new_vertex)) {  // (the early-rejection test of rule 0 has stored this very quad already)
+        wave_sync();
+        if (lane < 4) {
+            const int mp = lane == 0 ? mp0 : lane == 1 ? mp1 : lane == 2 ? mp2 : mp3;
+            c.sc->q[lane] = mp < 0 ? make_double2(new_point.x, new_point.y) : c.xy[mp];
+        }
+        wave_sync();
     }
-    wave_sync();
     MESHENV_STAMP(c, 3);
-    bool ok = quad_pass(c, prm, vr, p0, p1, p2, p3, bc0, bc1);
+    bool ok = quad_pass(c, prm, vr, p0, p1, p2, p3, bc0, bc1, have_pre && new_vertex, pre_qy, pre_qx);
     MESHENV_STAMP(c, 4);
     if (ok) {
         if (!have_filter) {  // rules -1 / +1 (and the same-point case): the filter pass on its own
@@ -1075,9 +1128,9 @@ __device__ __forceinline__ StepResult env_finish(Ctx &c, const Params &prm, cons
 }
 
 // step(action), B:113-263, on one wavefront
-__device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float a0, float a1, float a2)
+__device__ __forceinline__ StepResult env_step(Ctx &c, const DevState &S, float a0, float a1, float a2, const bool pre_reject)
 {
-    Decision d = env_check(c, S, a0, a1, a2);
+    Decision d = env_check(c, S, a0, a1, a2, pre_reject);
     if (d.ok) env_apply(c, S, d);
     return env_finish(c, S.prm, d);
 }
@@ -1230,7 +1283,7 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
             a0 = at[0]; a1 = at[1]; a2 = at[2];
         }
         const int n_before = c.n;
-        const StepResult r = env_step(c, S, a0, a1, a2);
+        const StepResult r = env_step(c, S, a0, a1, a2, kMulti);
 #ifdef MESHENV_STAMPS
         if (r.valid) st_valid += 1;
 #else
@@ -1403,7 +1456,7 @@ k_step_group(GroupArgs A)
         const EnvCounters cnt0 = S.cnt[env];
         load_env(c, S, env);
         const int n_before = c.n;
-        Decision d = env_check(c, S, a0, a1, a2);
+        Decision d = env_check(c, S, a0, a1, a2, false);
         if (!d.ok) {
             finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0);
         } else {
