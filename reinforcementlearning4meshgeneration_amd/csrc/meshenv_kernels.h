@@ -250,6 +250,7 @@ struct BqArgs {
     double half01, half23;  // 0.5*e0*e1 and 0.5*e2*e3 of Mesh.compute_area (C:935-950)
     double mesh_area;   // out; current_area is reduced by it before the observation is built (B:200)
     double b_reward;    // out
+    bool skip;          // the boundary-quality term is computed elsewhere (CU-group kernel: on a helper wavefront)
 };
 
 // find_next_state, B:504-571 -> PointEnvironment.get_neighbors C:1073-1082 + get_radius_points C:1184-1282.
@@ -283,7 +284,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     int ia = 0, ib = 0;
     {
         const bool j0 = lane < 6, j16 = lane >= 16 && lane < 22;
-        const bool m1 = bq.mode == 1, m2 = bq.mode == 2;
+        const bool m1 = bq.mode == 1 && !bq.skip, m2 = bq.mode == 2 && !bq.skip;
         const int k = lane - 10;
         const bool jwin = lane >= 10 && lane < (m1 ? 14 : 15) && (m1 || m2);
         const int wbase = m1 ? bqa : bqlo;
@@ -376,7 +377,8 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     int carry = 0;
     const int bqi = bq.a;
     const int w1 = wrapi(bqi + 1, n), w2 = wrapi(bqi + 2, n), w3 = wrapi(bqi - 1, n), w4 = wrapi(bqi - 2, n);
-    const P2 add_v = ldp(c, bq.mode == 1 ? bqi : 0);
+    const bool bq_scan = bq.mode == 1 && !bq.skip;
+    const P2 add_v = ldp(c, bq_scan ? bqi : 0);
     // traversal positions stage A had no lane for (rings longer than 58): their clockwise angles in full 64-lane
     // passes of their own, so that a 120-vertex ring costs one more transcendental pass, not two
     for (int o = kScanLanes + lane; o < n - 1; o += 64) {
@@ -393,7 +395,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         const P2 v = ldp(c, ii);
         const double angle = in_range ? c.ang_ord[ord] : 0.0;
         // (2) boundary-quality scan (mode 1): added(i) = near(i) && !added(i-1), M:355-357
-        if (bq.mode == 1) {
+        if (bq_scan) {
             const int i = base + lane;
             bool near = false;
             if (i < n && !(i == bqi || i == w1 || i == w2 || i == w3 || i == w4)) near = dist(add_v, ldp(c, i)) < dst;
@@ -488,7 +490,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         c.sc->robs[7 + 2 * j] = fa;
     }
     // ---- boundary quality (M:329-382 / M:392-426)
-    if (bq.mode != 0) {
+    if (bq.mode != 0 && !bq.skip) {
         double amin = 1e300;
         bool have = false;
         if (bq.ang0 < kPi / 3) { amin = bq.ang0; have = true; }
@@ -990,8 +992,11 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
 
 // The extraction itself, B:192-238 + find_next_state: element log, ring update, candidate list patch, reward,
 // next observation.  Runs on whichever wavefront holds the env's LDS region (c) and the decision.
-__device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d)
+// (upd_done != nullptr: CU-group kernel with a helper wavefront -- the reward is computed there from the post-update
+// ring; this wave publishes the updated ring through *upd_done and skips every reward-only computation)
+__device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d, volatile int *upd_done = nullptr)
 {
+    const bool has_helper = upd_done != nullptr;
     const Params &prm = S.prm;
     const int lane = c.lane;
     const int n = c.n, index = d.index;
@@ -1011,11 +1016,15 @@ __device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d
         double mn = e1 < e0 ? e1 : e0;
         mn = e2 < mn ? e2 : mn;
         mn = e3 < mn ? e3 : mn;
-        const double q1 = sqrt(2.0) * mn / (d13 > d02 ? d13 : d02);
-        double amn = ang1 < ang0 ? ang1 : ang0, amx = ang1 > ang0 ? ang1 : ang0;
-        amn = ang2 < amn ? ang2 : amn; amx = ang2 > amx ? ang2 : amx;
-        amn = ang3 < amn ? ang3 : amn; amx = ang3 > amx ? ang3 : amx;
-        e_reward = uniform_f64(sqrt(q1 * (amn / amx)));
+        e_reward = 0.0;
+        if (!has_helper) {
+            const double q1 = sqrt(2.0) * mn / (d13 > d02 ? d13 : d02);
+            double amn = ang1 < ang0 ? ang1 : ang0, amx = ang1 > ang0 ? ang1 : ang0;
+            amn = ang2 < amn ? ang2 : amn; amx = ang2 > amx ? ang2 : amx;
+            amn = ang3 < amn ? ang3 : amn; amx = ang3 > amx ? ang3 : amx;
+            e_reward = uniform_f64(sqrt(q1 * (amn / amx)));
+        }
+        bq.skip = has_helper;
         // Mesh.compute_area, C:935-950, left-to-right: ((0.5*e0)*e1)*sin(c1) + ((0.5*e2)*e3)*sin(c3);
         // corner_1 == corner angle 0, corner_3 == corner angle 2
         bq.half01 = uniform_f64(0.5 * e0 * e1);
@@ -1083,25 +1092,141 @@ __device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d
     MESHENV_STAMP(c, 6);
     c.ring_dirty = true;
     c.status &= ~(kStRm1Bad | kStRp1Bad);  // new state: forget the memoised rejections
+    if (has_helper) {  // ring coordinates and length are final: the helper may read them
+        wave_sync();
+        if (lane == 0) *upd_done = 1;
+    }
     const bool finished = c.n <= 5;  // B:232-238
     if (finished && c.n == 4) log_quad(c, S, c.id[0], c.id[1], c.id[2], c.id[3]);
     // current_area -= mesh_area (B:200) happens inside: the area needs sin(corner angles), a stage-B job
     find_next_state(c, S, bq);
     MESHENV_STAMP(c, 14);
-    const double mesh_area = bq.mesh_area;
-    // get_quality(mesh, 2), M:1733-1740
-    const double quality = e_reward + 1 * (bq.b_reward - 1);
-    // get_speed_penalty, B:434-450
-    const DomConst &dc = S.dom[c.dom];
+    if (!has_helper) {
+        const double mesh_area = bq.mesh_area;
+        // get_quality(mesh, 2), M:1733-1740
+        const double quality = e_reward + 1 * (bq.b_reward - 1);
+        // get_speed_penalty, B:434-450
+        const DomConst &dc = S.dom[c.dom];
+        const double min_area = dc.min_area, crit_area = dc.crit_area;
+        double speed = 0.0;
+        if (min_area <= mesh_area && mesh_area < crit_area) speed = (mesh_area - crit_area) / (crit_area - min_area);
+        else if (mesh_area < min_area) speed = -1.0;
+        d.reward += quality + speed;
+        if (finished) d.reward += 10.0;
+    }
+    if (finished) d.done = 1;
+}
+
+// The reward of a valid extraction on a helper wavefront of the CU-group kernel: quad quality from the scratch values
+// of the checks, element area, boundary quality on the POST-update ring (published by the update wave through
+// h.upd_done), speed penalty.  Same operations in the same order as the fused path of env_apply / find_next_state
+// (B:192-231, M:329-426, M:1733-1740, B:434-450), which the one-wave kernels keep.  c is carved on the env's LDS region.
+__device__ __forceinline__ double reward_on_helper(Ctx &c, const DevState &S, const Decision &d, int n_before, int dom,
+                                                   volatile int *upd_done)
+{
+    const int lane = c.lane;
+    const double e0 = c.sc->tmp2[0], e1 = c.sc->tmp2[1], e2 = c.sc->tmp2[2], e3 = c.sc->tmp2[3];
+    const double d02 = c.sc->tmp2[4], d13 = c.sc->tmp2[5];
+    const double ang0 = c.sc->ang[0], ang1 = c.sc->ang[1], ang2 = c.sc->ang[2], ang3 = c.sc->ang[3];
+    const double bq_ang0 = c.sc->tmp[8], bq_ang1 = c.sc->tmp[9];
+    double mn = e1 < e0 ? e1 : e0;
+    mn = e2 < mn ? e2 : mn;
+    mn = e3 < mn ? e3 : mn;
+    const double q1e = sqrt(2.0) * mn / (d13 > d02 ? d13 : d02);
+    double amn = ang1 < ang0 ? ang1 : ang0, amx = ang1 > ang0 ? ang1 : ang0;
+    amn = ang2 < amn ? ang2 : amn; amx = ang2 > amx ? ang2 : amx;
+    amn = ang3 < amn ? ang3 : amn; amx = ang3 > amx ? ang3 : amx;
+    const double e_reward = uniform_f64(sqrt(q1e * (amn / amx)));
+    const double half01 = uniform_f64(0.5 * e0 * e1), half23 = uniform_f64(0.5 * e2 * e3);
+    double sj = 0.0;
+    if (lane < 2) sj = sincos_nc(lane == 0 ? ang0 : ang2).s;  // the sincos of stage B
+    const double mesh_area = uniform_f64(half01 * lane_f64(sj, 0) + half23 * lane_f64(sj, 1));
+    // speed penalty, B:434-450
+    const DomConst &dc = S.dom[dom];
     const double min_area = dc.min_area, crit_area = dc.crit_area;
     double speed = 0.0;
     if (min_area <= mesh_area && mesh_area < crit_area) speed = (mesh_area - crit_area) / (crit_area - min_area);
     else if (mesh_area < min_area) speed = -1.0;
-    d.reward += quality + speed;
-    if (finished) {
-        d.reward += 10.0;
-        d.done = 1;
+
+    while (*upd_done == 0) __builtin_amdgcn_s_sleep(1);  // the update wave sets it unconditionally
+    wave_sync();
+    const bool m1 = d.new_vertex != 0;
+    const int n = m1 ? n_before : n_before - 2;
+    c.n = n;
+    const int bqa = m1 ? d.index : d.t0, bqb = m1 ? 0 : d.t1;
+    const int bqlo = bqa < bqb ? bqa : bqb;
+    // boundary-quality distances: the job lanes 8..14 of stage A
+    int ia = 0, ib = 0;
+    {
+        const int k = lane - 10;
+        const bool jwin = lane >= 10 && lane < (m1 ? 14 : 15);
+        const int wbase = m1 ? bqa : bqlo;
+        ia = jwin ? wrapi(wbase - 2 + k, n) : ia;
+        ib = jwin ? wrapi(wbase - 1 + k, n) : ib;
+        ia = (lane == 8 || lane == 9) ? bqa : ia;
+        ib = lane == 8 ? (m1 ? wrapi(bqa + 1, n) : bqb) : ib;
+        ib = (lane == 9 && m1) ? wrapi(bqa - 1, n) : ib;
     }
+    const double dv = dist(ldp(c, ia), ldp(c, ib));
+    const double bq_d0 = lane_f64(dv, 8), bq_d1 = lane_f64(dv, 9);
+    double bq_sum = lane_f64(dv, 10);
+    bq_sum += lane_f64(dv, 11);
+    bq_sum += lane_f64(dv, 12);
+    bq_sum += lane_f64(dv, 13);
+    const double bq_sum5 = bq_sum + lane_f64(dv, 14);
+    const double dst = uniform_f64(bq_d0 + bq_d1);
+    double amin = 1e300;
+    bool have = false;
+    if (bq_ang0 < kPi / 3) { amin = bq_ang0; have = true; }
+    if (bq_ang1 < kPi / 3) { amin = bq_ang1 < amin ? bq_ang1 : amin; have = true; }
+    const double q1 = have ? 3 * amin / kPi : 1.0;
+    double b_reward;
+    if (m1) {
+        // near-vertex scan of compute_boundary_quality: added(i) = near(i) && !added(i-1), M:355-357
+        double m_d = kInf;
+        int carry = 0;
+        const int bqi = bqa;
+        const int w1 = wrapi(bqi + 1, n), w2 = wrapi(bqi + 2, n), w3 = wrapi(bqi - 1, n), w4 = wrapi(bqi - 2, n);
+        const P2 add_v = ldp(c, bqi);
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            bool near = false;
+            if (i < n && !(i == bqi || i == w1 || i == w2 || i == w3 || i == w4)) near = dist(add_v, ldp(c, i)) < dst;
+            const unsigned long long m = __ballot(near);
+            bool added = false;
+            if (near) {
+                const unsigned long long zeros_below = ~m & ((1ULL << lane) - 1ULL);
+                if (zeros_below != 0ULL) {
+                    const int pz = 63 - __clzll((long long)zeros_below);
+                    added = ((lane - pz - 1) & 1) == 0;
+                } else {
+                    added = (lane & 1) == carry;
+                }
+            }
+            if (added) {
+                const double dd = seg_point_distance(ldp(c, wrapi(i + 1, n)), ldp(c, i), add_v);
+                m_d = dd < m_d ? dd : m_d;
+            }
+            carry = (int)((__ballot(added) >> 63) & 1ULL);
+        }
+        m_d = wave_min_f64(m_d);
+        const double targt_len = dst / 2;
+        const double mean_dist = bq_sum / 4;
+        const double smoothness = (targt_len < mean_dist ? targt_len : mean_dist) / (targt_len > mean_dist ? targt_len : mean_dist);
+        double q2 = 1.0;
+        if (m_d < 1e299) q2 = (m_d < 0.5 * dst) ? m_d / (0.5 * dst) : 1.0;
+        b_reward = cbrt(smoothness * q1 * q2);  // math.pow(x, 1/3)
+    } else {
+        const double targt_len = bq_d0;
+        const double mean_dist = bq_sum5 / 5;
+        const double smoothness = (targt_len < mean_dist ? targt_len : mean_dist) / (targt_len > mean_dist ? targt_len : mean_dist);
+        b_reward = sqrt(q1 * smoothness);  // math.pow(angle_quality * smoothness, 1/2)
+    }
+    const double quality = e_reward + 1 * (b_reward - 1);  // get_quality(mesh, 2), M:1733-1740
+    double reward = 0.0;
+    reward += quality + speed;
+    if (n <= 5) reward += 10.0;  // B:232-238
+    return reward;
 }
 
 // failed_num bookkeeping and the 100-failure truncation, B:253-263
@@ -1173,6 +1298,7 @@ __global__ void __launch_bounds__(64) k_init_domains(DevState S, int cap)
         c.stamp[i] = ok ? -i : kNotCand;
     }
     BqArgs bq;
+    bq.skip = false;
     bq.mode = 0; bq.a = 0; bq.b = 0; bq.ang0 = 0; bq.ang1 = 0; bq.q_ang0 = 0; bq.q_ang2 = 0; bq.half01 = 0; bq.half23 = 0;
     find_next_state(c, S, bq);
     for (int i = c.lane; i < c.n; i += 64) {
@@ -1335,7 +1461,9 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
 struct alignas(32) Handoff {
     int valid;  // the checks passed: an update is pending
     int simd;   // hardware SIMD the checking wave runs on
-    int env, n, ref, n_elem, failed, n_new, counter, status, dom, pad;
+    int upd_done;     // phase 2: the update wave has written the post-update ring (the helper may read it)
+    int helper_done;  // phase 2: the helper has finished reading the ring (an auto-reset may overwrite it)
+    int env, n, ref, n_elem, failed, n_new, counter, status, dom, pad[3];
     double bl, area, ct, st;
     EnvCounters cnt0;
     Decision d;
@@ -1384,8 +1512,11 @@ __device__ __forceinline__ StepOuts late_outs()
 }
 
 // reward / flags / observation of one finished step, auto-reset, state write-back, work counters
+// (helper_done != nullptr: the reward of this valid step is written by a helper wavefront, which also reads the ring:
+// an auto-reset waits for it before it overwrites the ring)
 __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, const Decision &d, const EnvCounters &cnt0,
-                                                 int n_before, int auto_reset, unsigned long long step0)
+                                                 int n_before, int auto_reset, unsigned long long step0,
+                                                 volatile int *helper_done = nullptr)
 {
     const StepResult r = env_finish(c, S.prm, d);
     const int env = c.env;
@@ -1395,17 +1526,24 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
     uint8_t *__restrict__ done = o.done;
     uint8_t *__restrict__ complete = o.complete;
     float *__restrict__ term_obs = o.term_obs;
+    const bool has_helper = helper_done != nullptr;
     if (c.lane == 0) {
-        reward[env] = r.reward;
+        if (!has_helper) reward[env] = r.reward;
         done[env] = (uint8_t)r.done;
         complete[env] = (uint8_t)r.complete;
     }
     if (r.done) {
         if (term_obs && c.lane < kObsDim) term_obs[(size_t)env * kObsDim + c.lane] = c.obs;
-        if (auto_reset) reset_from_domain(c, S);
+        if (auto_reset) {
+            if (has_helper) {
+                while (*helper_done == 0) __builtin_amdgcn_s_sleep(1);  // the helper sets it unconditionally
+                wave_sync();
+            }
+            reset_from_domain(c, S);
+        }
     }
     if (c.lane < kObsDim) obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
-    if (S.msg && c.lane < 21) {  // the exchange message of the multi-GPU path, written in place of separate pack kernels
+    if (S.msg && c.lane < 21 && !(has_helper && c.lane == 18)) {  // the exchange message of the multi-GPU path
         const float v = c.lane < kObsDim ? c.obs : (c.lane == 18 ? (float)r.reward : (c.lane == 19 ? (float)r.done : (float)r.complete));
         S.msg[(size_t)env * 21 + c.lane] = v;
     }
@@ -1468,6 +1606,8 @@ k_step_group(GroupArgs A)
                 h.bl = c.bl; h.area = c.area; h.ct = c.ct; h.st = c.st;
                 h.cnt0 = cnt0;
                 h.d = d;
+                h.upd_done = 0;
+                h.helper_done = 0;
             }
         }
     }
@@ -1504,23 +1644,54 @@ k_step_group(GroupArgs A)
     const int my_simd = (sm1 & wbit) ? 1 : (sm2 & wbit) ? 2 : (sm3 & wbit) ? 3 : 0;
     const unsigned mine = my_simd == 0 ? sm0 : my_simd == 1 ? sm1 : my_simd == 2 ? sm2 : sm3;
     const bool balanced = __popc(sm0) * 4 == G && __popc(sm1) * 4 == G && __popc(sm2) * 4 == G && __popc(sm3) * 4 == G;
-    int src = -1;
+    // roles: deal index j < m -> update of the j-th pending env; m <= j < 2m -> reward helper of the (j-m)-th one (only
+    // when every update gets a helper: 2m <= G).  The helper runs concurrently on another wavefront, usually an idle SIMD.
+    int src = -1, hsrc = -1;
+#ifdef MESHENV_NO_HELPER
+    const bool helpers = false;
+#else
+    const bool helpers = balanced && G >= 4 && 2 * m <= G;
+#endif
     if (balanced && G >= 4) {
         const int j = __popc(mine & ((1u << wave) - 1u)) * 4 + my_simd;  // my turn in the deal
-        if (j < m) {
+        const int k = j < m ? j : (helpers && j < 2 * m ? j - m : -1);
+        if (k >= 0) {
             unsigned rest = vmask;
-            for (int t = 0; t < j; t++) rest &= rest - 1u;  // drop the j lowest pending waves
-            src = __ffs((int)rest) - 1;
+            for (int t = 0; t < k; t++) rest &= rest - 1u;  // drop the k lowest pending waves
+            const int which = __ffs((int)rest) - 1;
+            if (j < m) src = which;
+            else hsrc = which;
         }
     } else if (vmask & (1u << wave)) {
         src = wave;  // waves not spread evenly over the SIMDs: everybody keeps its own env
     }
-    if (src < 0) return;
+    if (src < 0 && hsrc < 0) return;
+
+    if (hsrc >= 0) {
+        // ---- phase 2, helper: the reward of env ho[hsrc]
+        Ctx c;
+        carve_lds(c, (char *)smem + (size_t)hsrc * env_bytes, cap);
+        Handoff &h = ho[hsrc];
+        c.lane = threadIdx.x & 63;
+        Decision d = h.d;
+        d.index = uniform_i32(d.index); d.new_vertex = uniform_i32(d.new_vertex);
+        d.t0 = uniform_i32(d.t0); d.t1 = uniform_i32(d.t1);
+        const int henv = uniform_i32(h.env);
+        const double rew = reward_on_helper(c, S, d, uniform_i32(h.n), uniform_i32(h.dom), &h.upd_done);
+        wave_sync();
+        if (c.lane == 0) {
+            *(volatile int *)&h.helper_done = 1;
+            const StepOuts o = late_outs();
+            o.reward[henv] = rew;
+            if (S.msg) S.msg[(size_t)henv * 21 + 18] = (float)rew;
+        }
+        return;
+    }
 
     // ---- phase 2: the update of env ho[src], in place in its LDS region
     Ctx c;
     carve_lds(c, (char *)smem + (size_t)src * env_bytes, cap);
-    const Handoff &h = ho[src];
+    Handoff &h = ho[src];
     c.lane = threadIdx.x & 63;
     c.env = uniform_i32(h.env);
     c.base = (size_t)c.env * S.cap;
@@ -1537,11 +1708,11 @@ k_step_group(GroupArgs A)
     d.ok = 1;
     const EnvCounters cnt0 = h.cnt0;
     const int n_before = c.n;
-    env_apply(c, S, d);
+    env_apply(c, S, d, helpers ? &h.upd_done : nullptr);
 #ifdef MESHENV_STAMPS
     const unsigned long long dbg_t8 = __builtin_amdgcn_s_memrealtime();
 #endif
-    finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0);
+    finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0, helpers ? &h.helper_done : nullptr);
 #ifdef MESHENV_STAMPS
     if (c.lane == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
