@@ -165,20 +165,27 @@ __device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env)
     wave_sync();
 }
 
-__device__ __forceinline__ void store_env(Ctx &c, const DevState &S)
+// ring arrays LDS -> HBM (slots [0, n))
+__device__ __forceinline__ void store_ring(const Ctx &c, const DevState &S)
+{
+    double2 *gxy = S.ring_xy + c.base;
+    int32_t *gid = S.ring_id + c.base;
+    double *gkey = S.ring_key + c.base;
+    int32_t *gst = S.ring_stamp + c.base;
+    for (unsigned i = (unsigned)c.lane; i < (unsigned)c.n; i += 64u) {
+        gxy[i] = c.xy[i];
+        gid[i] = c.id[i];
+        gkey[i] = c.key[i];
+        gst[i] = c.stamp[i];
+    }
+}
+
+// (ring_elsewhere: the ring arrays of this step are written back by the helper wavefront of the CU-group kernel)
+__device__ __forceinline__ void store_env(Ctx &c, const DevState &S, bool ring_elsewhere = false)
 {
     wave_sync();
     if (c.ring_dirty) {
-        double2 *gxy = S.ring_xy + c.base;
-        int32_t *gid = S.ring_id + c.base;
-        double *gkey = S.ring_key + c.base;
-        int32_t *gst = S.ring_stamp + c.base;
-        for (unsigned i = (unsigned)c.lane; i < (unsigned)c.n; i += 64u) {
-            gxy[i] = c.xy[i];
-            gid[i] = c.id[i];
-            gkey[i] = c.key[i];
-            gst[i] = c.stamp[i];
-        }
+        if (!ring_elsewhere) store_ring(c, S);
         if (c.lane < kObsDim) S.obs_cache[(size_t)c.env * kObsDim + c.lane] = c.obs;
     }
     if (c.lane == 0) {
@@ -1547,7 +1554,7 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
         const float v = c.lane < kObsDim ? c.obs : (c.lane == 18 ? (float)r.reward : (c.lane == 19 ? (float)r.done : (float)r.complete));
         S.msg[(size_t)env * 21 + c.lane] = v;
     }
-    store_env(c, S);
+    store_env(c, S, has_helper && !r.done);
     if ((r.valid || (r.done && auto_reset)) && c.lane == 0) {  // the ring length changes after this step
         EnvCounters k = cnt0;
         k.sum_n += (unsigned long long)n_before * (step0 + 1ULL - k.last_change);
@@ -1679,6 +1686,11 @@ k_step_group(GroupArgs A)
         const int henv = uniform_i32(h.env);
         const double rew = reward_on_helper(c, S, d, uniform_i32(h.n), uniform_i32(h.dom), &h.upd_done);
         wave_sync();
+        if (c.n > 5) {  // not the end of the episode: the ring is final, write it back here (off the update wave's path)
+            c.env = henv;
+            c.base = (size_t)henv * S.cap;
+            store_ring(c, S);
+        }
         if (c.lane == 0) {
             *(volatile int *)&h.helper_done = 1;
             const StepOuts o = late_outs();
