@@ -1660,8 +1660,24 @@ k_step_group(GroupArgs A)
     const bool helpers = balanced && G >= 4 && 2 * m <= G;
 #endif
     if (balanced && G >= 4) {
-        const int j = __popc(mine & ((1u << wave) - 1u)) * 4 + my_simd;  // my turn in the deal
-        const int k = j < m ? j : (helpers && j < 2 * m ? j - m : -1);
+        const int r = __popc(mine & ((1u << wave) - 1u));  // my rank among the waves of my SIMD
+        const int j = r * 4 + my_simd;                     // my turn in the deal
+        int k = j < m ? j : -1;
+        if (helpers && j >= m) {
+            // Helpers go to the SIMDs that carry fewer updates.  SIMD s runs ceil((m - s) / 4) updates; the number of
+            // helpers it takes, per m = 1..8 (nibble s of the entry): an update counts ~3 helper units, and
+            // updates + helpers <= 4 waves per SIMD (G = 16).  With G = 8 (two waves per SIMD) m <= 4 and the entries
+            // still fit.  Which helper serves which pending env does not matter: they are numbered SIMD-major.
+            // (G = 8: m = 3 -> [0,0,1,2], two waves per SIMD)
+            const unsigned long long t_lo = G >= 16 ? 0x1111300011000010ULL : 0x1111210011000010ULL;  // m = 1..4
+            const unsigned long long t_hi = 0x2222321133001220ULL;                                    // m = 5..8
+            const unsigned hcw = (unsigned)(((m <= 4 ? t_lo : t_hi) >> (16 * ((m - 1) & 3))) & 0xffffULL);
+            const int mains_here = (m + 3 - my_simd) >> 2;
+            const int t = r - mains_here;
+            const int here = (int)((hcw >> (4 * my_simd)) & 15u);
+            const int below = my_simd == 0 ? 0 : (int)((hcw & 15u) + (my_simd > 1 ? ((hcw >> 4) & 15u) : 0u) + (my_simd > 2 ? ((hcw >> 8) & 15u) : 0u));
+            if (t >= 0 && t < here) k = below + t;
+        }
         if (k >= 0) {
             unsigned rest = vmask;
             for (int t = 0; t < k; t++) rest &= rest - 1u;  // drop the k lowest pending waves

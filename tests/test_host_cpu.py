@@ -108,3 +108,33 @@ def test_spaces_and_sharding():
         assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
         sizes = [hi - lo for lo, hi in blocks]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_helper_placement_table_of_the_group_kernel():
+    """csrc/meshenv_kernels.h deals the m pending updates of a workgroup and their m reward helpers over the waves of
+    four SIMDs with a nibble table; this mirrors the formulas and checks, for every group size and m, that each pending
+    env gets exactly one update wave and exactly one helper, on distinct waves, within the waves a SIMD has."""
+    import re
+    src = open(os.path.join(ROOT, "reinforcementlearning4meshgeneration_amd", "csrc", "meshenv_kernels.h")).read()
+    t16, t8 = re.search(r"t_lo = G >= 16 \? (0x[0-9a-f]+)ULL : (0x[0-9a-f]+)ULL", src).groups()
+    t_hi = int(re.search(r"t_hi = (0x[0-9a-f]+)ULL", src).group(1), 16)
+    for G in (4, 8, 16):
+        t_lo = int(t16 if G >= 16 else t8, 16)
+        per_simd = G // 4
+        for m in range(1, G // 2 + 1):
+            hcw = ((t_lo if m <= 4 else t_hi) >> (16 * ((m - 1) & 3))) & 0xffff
+            mains, helpers = [], []
+            for s in range(4):
+                for r in range(per_simd):
+                    j = 4 * r + s
+                    if j < m:
+                        mains.append(j)
+                        continue
+                    mains_here = (m + 3 - s) >> 2
+                    t = r - mains_here
+                    here = (hcw >> (4 * s)) & 15
+                    below = sum((hcw >> (4 * q)) & 15 for q in range(s))
+                    if 0 <= t < here:
+                        helpers.append(below + t)
+            assert sorted(mains) == list(range(m)), (G, m, mains)
+            assert sorted(helpers) == list(range(m)), (G, m, helpers)
