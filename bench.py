@@ -35,30 +35,73 @@ def algorithmic_bytes(steps, valid, sum_ring, sum_ring_valid):
     return 28 * sum_ring + 158 * steps + 28 * sum_ring_valid + 48 * valid
 
 
-def pmc_traffic(n_envs):
+def pmc_traffic(n_envs, workload="boundary0"):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/): FETCH_SIZE and
     WRITE_SIZE are collected in separate --pmc runs, in KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     gfx950.  None when no profile of this workload is committed (bench.py cannot run the profiler on itself)."""
-    best = None
+    d, src = committed_profile(n_envs, workload)
+    if d is None:
+        return None, None
+    return d["hbm_traffic_bytes_per_launch"]["gfx950_corrected_(2*FETCH+WRITE)*1024"], src
+
+
+def committed_profile(n_envs, workload):
+    """Newest profiles/*_summary.json (tools/summarize_profile.py) taken on this workload, or (None, None)."""
+    best = (None, None)
     pdir = os.path.join(ROOT, "profiles")
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
             if f.endswith("_summary.json"):
                 try:
                     d = json.load(open(os.path.join(pdir, f)))
-                    if d.get("n_envs_per_gpu", d.get("bench_line_under_rocprof", {}).get("config", {}).get("n_envs_per_gpu")) == n_envs:
-                        best = (d["hbm_traffic_bytes_per_launch"]["gfx950_corrected_(2*FETCH+WRITE)*1024"], "profiles/" + f)
+                    cfg = d.get("bench_line_under_rocprof", {}).get("config", {})
+                    if d.get("n_envs_per_gpu", cfg.get("n_envs_per_gpu")) == n_envs and d.get("workload_key", "boundary0") == workload:
+                        best = (d, "profiles/" + f)
                 except Exception:
                     pass
-    return best if best else (None, None)
+    return best
 
 
-def cpu_baseline(n_envs, seed, budget_s=12.0):
+def instruction_side(n_envs, workload, launch_us):
+    """The instruction-side view SURVEY 8(d) asks for next to the HBM fraction, from the committed SQ counter pass of this
+    same command (bench.py cannot run the profiler on itself): VALU instructions per wave, the share of wave-cycles
+    spent waiting / issuing VALU, and the launch's VALU issue floor -- every VALU instruction of the launch issued
+    back to back at 4 cycles (one wave's issue cost, MI355X_MICROARCH.md) over the chip's 1024 SIMDs at 2.4 GHz."""
+    d, src = committed_profile(n_envs, workload)
+    if d is None:
+        return None
+    p = d.get("pmc_per_launch_mean", {})
+    try:
+        waves, valu, cyc = p["SQ_WAVES"], p["SQ_INSTS_VALU"], p["SQ_WAVE_CYCLES"]
+        floor_us = valu * 4.0 / (1024 * 2.4e3)
+        return {"source": src, "valu_insts_per_wave": valu / waves, "salu_insts_per_wave": p["SQ_INSTS_SALU"] / waves,
+                "lds_insts_per_wave": p["SQ_INSTS_LDS"] / waves,
+                "wait_frac": p["SQ_WAIT_ANY"] / cyc, "valu_active_frac": p["SQ_ACTIVE_INST_VALU"] / cyc,
+                "issue_stall_frac": p["SQ_WAIT_INST_ANY"] / cyc,
+                "valu_issue_floor_us": floor_us, "valu_issue_frac_of_launch": floor_us / launch_us if launch_us else None,
+                "bound": "dependent-issue latency of the waves that extract an element (wait_frac), not VALU issue rate "
+                         "and not HBM"}
+    except KeyError:
+        return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(n_envs, seed, doms, env_domain, wl, budget_s=12.0):
     """The CPU oracle (oracle/meshenv_ref.c, plain C, host libm) on the same workload, bounded sample."""
-    from oracle.ref_lib import RefBatch, RefEnv
-    from reinforcementlearning4meshgeneration_amd.domains import boundary
+    from oracle.ref_lib import RefBatch, RefEnv, math_calls
 
-    envs = [RefEnv.from_points(boundary(0), cap_new=64) for _ in range(n_envs)]
+    dom_of = env_domain if env_domain is not None else np.zeros(n_envs, np.int32)
+    envs = [RefEnv.from_points(doms[int(dom_of[k])], cap_new=64) for k in range(n_envs)]
     batch = RefBatch(envs)
     batch.reset()
     rng = np.random.default_rng(seed)
@@ -73,7 +116,9 @@ def cpu_baseline(n_envs, seed, budget_s=12.0):
 
     dt = run(4, 1)  # calibrate
     T1 = max(8, min(2000, int(0.5 * budget_s / (dt / 4))))
+    math_calls(reset=True)
     dt1 = run(T1, 1)
+    n_atan2, n_sin, n_cos = math_calls(reset=True)
     one = n_envs * T1 / dt1
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, int(os.environ.get("MESHENV_CPU_THREADS", "16"))))
@@ -81,9 +126,20 @@ def cpu_baseline(n_envs, seed, budget_s=12.0):
     Tn = max(8, min(4000, int(0.5 * budget_s / (dtc / 2))))
     dtn = run(Tn, cores)
     allc = n_envs * Tn / dtn
-    return dict(value=one, unit="env-steps/s", cores=1, kind="port",
-                sample=f"{n_envs} boundary() envs x {T1} uniform-random vector steps, oracle/meshenv_ref.c, 1 thread",
-                all_cores=dict(value=allc, cores=cores, sample=f"{n_envs} envs x {Tn} steps, OpenMP over envs"))
+    per = float(n_envs * T1)
+    return dict(value=one, unit="env-steps/s", cores=1, kind="port", cpu_model=cpu_model(),
+                sample=f"{n_envs} envs on {wl} x {T1} uniform-random vector steps, oracle/meshenv_ref.c, 1 thread",
+                all_cores=dict(value=allc, cores=cores, sample=f"{n_envs} envs x {Tn} steps, OpenMP over envs"),
+                fp64_transcendentals_per_env_step=dict(
+                    atan2=n_atan2 / per, sin=n_sin / per, cos=n_cos / per,
+                    note="libm calls of the reference algorithm (the oracle restates it call for call) on this sample; "
+                         "the HIP kernels evaluate fewer (exact early rejects, cached observation of unchanged states)"))
+
+
+def timing_group(K, time_every):
+    """Launches per HIP-event bracket: the largest k <= time_every such that at least one bracket closes within K
+    launches (meshenv_set_timing brackets launches [0, k), [2k, 3k), ... of the timed region)."""
+    return max(1, min(int(time_every), int(K)))
 
 
 def main():
@@ -102,6 +158,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-process flow on a one-GPU box together with MESHENV_BENCH_DEVICE=0)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--clock-warmup-ms", type=float, default=250.0,
+                    help="GPU busy time on a scratch handle before the warm-up steps (raises the clock from idle; 0 = off)")
     ap.add_argument("--time-every", type=int, default=25,
                     help="HIP events bracket every other group of k consecutive launches of the timed region (an event pair costs ~8 us of stream time, so k is kept large)")
     args = ap.parse_args()
@@ -138,16 +196,16 @@ def main():
         return [tuple(p) for p in tr["domain_xy"]]
 
     if args.workload == "boundary0":
-        doms, env_domain, wl = [boundary(0)], None, "boundary() (general/polygon.py:79-83, 30-vertex ring)"
+        doms, env_domain, wl, wl_short = [boundary(0)], None, "boundary() (general/polygon.py:79-83, 30-vertex ring)", "boundary()"
     elif args.workload == "d1":
-        doms, env_domain, wl = [golden_domain("boundary16_biased_s2")], None, "ui/domains/boundary16.json (d1, 120-vertex ring)"
+        doms, env_domain, wl, wl_short = [golden_domain("boundary16_biased_s2")], None, "ui/domains/boundary16.json (d1, 120-vertex ring)", "boundary16.json (d1)"
     elif args.workload == "mixed":
         doms = [golden_domain(x) for x in ("boundary16_biased_s2", "boundary15_biased_s5", "test1_biased_s42")]
-        env_domain, wl = np.arange(n, dtype=np.int32) % 3, "d1/d2/d3 interleaved (120/196/272-vertex rings)"
+        env_domain, wl, wl_short = np.arange(n, dtype=np.int32) % 3, "d1/d2/d3 interleaved (120/196/272-vertex rings)", "mixed d1/d2/d3"
     else:
         from reinforcementlearning4meshgeneration_amd.domains import random_domain
         doms = [random_domain(1000 + rank * n + k) for k in range(n)]
-        env_domain, wl = np.arange(n, dtype=np.int32), "one random star-shaped ring per env (GenerateRandomPolygon restated, densified)"
+        env_domain, wl, wl_short = np.arange(n, dtype=np.int32), "one random star-shaped ring per env (GenerateRandomPolygon restated, densified)", "GenerateRandomPolygon"
     env = MeshVecEnv(doms, n_envs=n, env_domain=env_domain, device=local_rank, auto_reset=True, log_capacity=0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -159,46 +217,62 @@ def main():
     from reinforcementlearning4meshgeneration_amd import sharding
     do_gather = world > 1 or os.environ.get("MESHENV_BENCH_FORCE_GATHER") == "1"
     GS = max(1, args.gather_every)
+    coll = "RCCL" if args.backend == "nccl" else args.backend
+    xch = None
     if do_gather:
         # The step kernel writes the [n, 21] message of step t into slot t % GS of a [GS, n, 21] bucket; one
         # all_gather_into_tensor per bucket (RCCL, its own stream) overlaps the next bucket's steps -- actors run their
         # own policy copy, the gathered transitions feed the learner's replay buffer.  Two buckets, so a
         # bucket is only rewritten after its collective has completed.  One collective per GS steps keeps the
-        # ~25 us host cost of a collective call off the per-step path.
-        on_dev = args.backend == "nccl"
-        buckets = [torch.zeros((GS, n, sharding.MSG_DIM), dtype=torch.float32, device=dev) for _ in range(2)]
-        gdev = dev if on_dev else torch.device("cpu")
-        gath = [torch.empty((world * GS, n, sharding.MSG_DIM), dtype=torch.float32, device=gdev) for _ in range(2)]  # rank-major
-        works = [None, None]
+        # ~25 us host cost of a collective call off the per-step path (sharding.BucketExchange, covered on CPU by
+        # tests/test_distributed_cpu.py).
+        xch = sharding.BucketExchange(dist, torch, n, GS, dev, stage_to_cpu=args.backend != "nccl")
+
+    # The timed loop calls the C-ABI entry point directly (the buffers are bound once): MeshVecEnv.step() adds argument
+    # checks and a torch stream lookup per call, microseconds of host time that a 16 us launch cannot hide.
+    env._bind_stream()
+    L, handle = env._L, env._handle
+    p_obs, p_rew, p_done, p_comp, p_term = (env.obs.data_ptr(), env.reward.data_ptr(), env.done.data_ptr(),
+                                            env.complete.data_ptr(), env.terminal_obs.data_ptr())
+    a_ptr, a_stride = actions.data_ptr(), n * 3 * 4
 
     def one_step(t):
-        if do_gather:
-            slot, b = t % GS, (t // GS) & 1
-            if slot == 0 and works[b] is not None:
-                works[b].wait()          # stream-level wait for the collective that last used this bucket
-                works[b] = None
-            env.set_packed_output(buckets[b][slot])
-        env.step(actions[t])
-        if do_gather and slot == GS - 1:
-            if on_dev:
-                works[b] = dist.all_gather_into_tensor(gath[b], buckets[b], async_op=True)
-            else:
-                dist.all_gather_into_tensor(gath[b], buckets[b].cpu())
+        if xch is not None:
+            env.set_packed_output(xch.slot(t))
+        rc = L.meshenv_step(handle, a_ptr + t * a_stride, p_obs, p_rew, p_done, p_comp, p_term, 1)
+        if rc != 0:
+            env._check(rc, "meshenv_step")
+        if xch is not None:
+            xch.after_step(t)
 
     def drain():
-        if do_gather:
-            for b in (0, 1):
-                if works[b] is not None:
-                    works[b].wait()
-                    works[b] = None
+        if xch is not None:
+            xch.drain()
+
+    # Clock warm-up (not steps of the measured environments): an idle MI355X sits at its lowest clock and a K = 20 timed
+    # region lasts 0.3 ms -- too short for the clock to rise.  A scratch handle runs fused rollouts for ~0.25 s first.
+    if args.clock_warmup_ms > 0:
+        scratch = MeshVecEnv([boundary(0)], n_envs=4096, device=local_rank, auto_reset=True, log_capacity=0)
+        sa = actions[:min(32, K + W), :min(n, 4096)].contiguous()
+        if sa.shape[1] < 4096:
+            sa = sa.repeat(1, (4096 + sa.shape[1] - 1) // sa.shape[1], 1)[:, :4096].contiguous()
+        t_w = time.perf_counter()
+        while (time.perf_counter() - t_w) * 1e3 < args.clock_warmup_ms:
+            for _ in range(8):
+                scratch.rollout(sa)
+            torch.cuda.synchronize()
+        scratch.close()
 
     for t in range(W):
         one_step(t)
     drain()
     torch.cuda.synchronize()
     c0 = env.counters()
+    # HIP events bracket groups of k consecutive launches on the launch stream.  k never exceeds K, so at least one
+    # group closes for every K >= 1 (a driver run with --steps 20 gets one group of 20, not an empty record).
+    time_k = timing_group(K, args.time_every)
     if not args.no_kernel_timing:
-        env.set_timing(args.time_every)
+        env.set_timing(time_k)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -227,27 +301,34 @@ def main():
     total_steps = K * n * world
     value = total_steps / elapsed
     out = {
-        "metric": "env-steps/sec at N_envs=4096 per GPU, boundary() domain",
+        "metric": f"env-steps/sec at N_envs={n} per GPU, {wl_short} domain, {world} MI355X",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n} vectorised envs per GPU on {wl}, "
                                "uniform-random float32 actions resident in HBM, auto-reset, one meshenv_step launch "
-                               "per vector step" + (f", + one async RCCL all-gather per {GS} steps of the [{GS},n,21] f32 obs/reward/done bucket written by the kernel" if world > 1 else ""),
+                               "per vector step" + (f", + one async {coll} all-gather per {GS} steps of the [{GS},n,21] f32 obs/reward/done bucket written by the kernel" if do_gather else ""),
                    "n_envs_per_gpu": n, "n_envs_total": n * world, "parallelism": f"env-shard x{world}",
+                   "clock_warmup_ms": args.clock_warmup_ms,
                    "valid_action_rate": d["valid"] / max(1, d["steps"]), "mean_ring_len": d["sum_ring"] / max(1, d["steps"])},
     }
+    # roofline of the dominant kernel (the one-step kernel): never omitted -- without a closed event group (timing
+    # switched off) the per-launch time falls back to the wall clock of the timed region
+    alg = algorithmic_bytes(d["steps"], d["valid"], d["sum_ring"], d["sum_ring_valid"]) / K
     if kt is not None and len(kt):
-        alg = algorithmic_bytes(d["steps"], d["valid"], d["sum_ring"], d["sum_ring_valid"]) / K
-        avg_ms = float(np.mean(kt))
-        achieved = alg / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(n)
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                           "kernel": ("meshenv::k_step_group<%d, true>" % env.group_size) if env.group_size > 1 else "meshenv::k_step<false, true>",
-                           "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": float(np.min(kt)) * 1e3,
-                           "algorithmic_bytes_per_launch": alg, "launches_timed": int(len(kt)) * args.time_every,
-                           "timing": "HIP events on the launch stream bracketing groups of %d consecutive launches" % args.time_every}
+        avg_ms, min_ms, n_timed = float(np.mean(kt)), float(np.min(kt)), int(len(kt)) * time_k
+        timing = "HIP events on the launch stream bracketing groups of %d consecutive launches" % time_k
+    else:
+        avg_ms = min_ms = 1e3 * elapsed / K
+        n_timed, timing = K, "wall (no HIP-event group recorded): elapsed / steps, includes host launch gaps"
+    achieved = alg / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(n, args.workload)
+    out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                       "kernel": ("meshenv::k_step_group<%d, true>" % env.group_size) if env.group_size > 1 else "meshenv::k_step<false, true>",
+                       "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": min_ms * 1e3,
+                       "algorithmic_bytes_per_launch": alg, "launches_timed": n_timed, "timing": timing,
+                       "instruction_side": instruction_side(n, args.workload, avg_ms * 1e3)}
     if world == 1 and args.workload == "boundary0":
         # informational: the same steps fused T per launch (meshenv_rollout, open-loop actions); never part of `value`
         Tr = min(64, K + W)
@@ -261,7 +342,8 @@ def main():
                                 "note": "meshenv_rollout: T consecutive steps per kernel launch, open-loop only"}
     env.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n, seed=99)
+        out["cpu_baseline"] = cpu_baseline(n, 99, doms, env_domain, wl)
+        out["cpu_baseline"]["gpu_over_cpu_all_cores"] = value / out["cpu_baseline"]["all_cores"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if pg_up:

@@ -31,6 +31,23 @@
 
 #define PI 3.141592653589793 /* math.pi */
 
+/* Transcendental call counters of the calling thread (bench.py reports the reference algorithm's fp64 atan2 / sin /
+ * cos count per env-step next to the roofline).  One thread-local increment per libm call. */
+static __thread uint64_t g_math_calls[3];
+static inline double c_atan2(double y, double x) { g_math_calls[0]++; return atan2(y, x); }
+static inline double c_sin(double x) { g_math_calls[1]++; return sin(x); }
+static inline double c_cos(double x) { g_math_calls[2]++; return cos(x); }
+void meshenv_ref_math_calls(uint64_t *out /*[3]: atan2, sin, cos*/, int reset)
+{
+    for (int i = 0; i < 3; i++) {
+        out[i] = g_math_calls[i];
+        if (reset) g_math_calls[i] = 0;
+    }
+}
+#define atan2 c_atan2
+#define sin c_sin
+#define cos c_cos
+
 typedef struct {
     double x, y;
 } P2;

@@ -64,6 +64,10 @@ void meshenv_ref_step_batch(RefEnv **envs, int n, const float *actions, float *o
                             uint8_t *done, uint8_t *is_complete, float *terminal_obs, int auto_reset,
                             int threads);
 
+/* libm calls made by the CALLING thread since the last reset: out[3] = atan2, sin, cos (bench.py reports the
+ * reference algorithm's fp64 transcendental count per env-step; meaningful for threads == 1 runs) */
+void meshenv_ref_math_calls(uint64_t *out, int reset);
+
 /* primitives exported for unit tests */
 double meshenv_ref_round4_py(double x);
 double meshenv_ref_round4_np(double x);

@@ -51,6 +51,8 @@ def lib():
     L.meshenv_ref_get_elements.argtypes = [C.c_void_p, _i32p, _f64p, _i32p, _i32p]
     L.meshenv_ref_step_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, _f32p, _f32p, _f64p, _u8p, _u8p,
                                          C.c_void_p, C.c_int, C.c_int]
+    L.meshenv_ref_math_calls.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.meshenv_ref_math_calls.restype = None
     L.meshenv_ref_round4_py.restype = C.c_double
     L.meshenv_ref_round4_py.argtypes = [C.c_double]
     L.meshenv_ref_round4_np.restype = C.c_double
@@ -65,6 +67,13 @@ def lib():
     L.meshenv_ref_quality_stats.argtypes = [_f64p, C.c_int, _f64p]
     _lib = L
     return L
+
+
+def math_calls(reset=False):
+    """(atan2, sin, cos) libm calls made by this thread since the last reset."""
+    out = (C.c_uint64 * 3)()
+    lib().meshenv_ref_math_calls(out, int(bool(reset)))
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def element_quality(quad_xy):

@@ -11,7 +11,6 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_NAME = "libmeshenv_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 SOURCES = ["meshenv_hip.hip"]
-HEADERS = ["meshenv_geom.h", "meshenv_state.h", "meshenv_kernels.h"]
 ARCH = "gfx950"
 
 # -ffp-contract=off: the reference is CPython float arithmetic, which never fuses a*b+c.
@@ -31,7 +30,8 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    # every header of csrc/ is a dependency of the one translation unit (meshenv_hip.hip includes them all)
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".hip"))]
     deps.append(os.path.join(os.path.dirname(PKG_DIR), "include", "meshenv.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -33,6 +33,7 @@ struct MeshEnv {
     DevCold cold{};  // host copy of *S.cold
     bool default_params = true;  // geometry constants are the reference's: literal-constant kernel instantiations
     size_t lds = 0;
+    int n_cu = 256;       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int group = 1;        // environments (wavefronts) per workgroup of the single-step kernel
     size_t group_lds = 0;
     std::vector<int32_t> dom_off_host, env_dom_host;
@@ -69,6 +70,28 @@ int dev_alloc(MeshEnv *h, T **out, size_t count)
     *out = (T *)p;
     return MESHENV_OK;
 }
+
+// Every entry point that launches, copies or synchronises runs on the HANDLE's device and leaves the caller's current
+// device as it found it (a process may hold handles on several GPUs, and torch tracks its own current device).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device);
+        else prev = -1;  // nothing to restore
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define MESHENV_ON_DEVICE(h)              \
+    DeviceGuard _guard((h)->device);      \
+    HIP_TRY(h, _guard.err)
 
 int fail_arg(MeshEnv *h, const char *msg)
 {
@@ -113,7 +136,7 @@ const char *meshenv_last_error(const MeshEnv *h) { return h ? h->err.c_str() : g
 void meshenv_destroy(MeshEnv *h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -187,7 +210,8 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
         }                                                                               \
     } while (0)
 
-    CREATE_HIP(hipSetDevice(device));
+    DeviceGuard guard(device);
+    CREATE_HIP(guard.err);
     // The attribute is per function, not per handle: always raise it to the CU's full 160 KB so that a later handle with
     // shorter rings cannot lower the cap under an earlier one.
     constexpr int kLdsCap = 160 * 1024;
@@ -205,18 +229,22 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
     // boundary(): 4096 envs 20.2 -> 19.4 us/step (G = 16), 2048 envs 16.5 -> 16.0 (G = 8), but 8192 envs
     // 25.0 -> 34.6 and 65536 envs 103 -> 231 us/step, where throughput, not the slowest wave, sets the time.
     {
+        int n_cu = 256;  // MI355X; read from the device so that a partitioned GPU (CPX / fewer CUs) keeps one workgroup per CU
+        CREATE_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
+        if (n_cu <= 0) n_cu = 256;
+        h->n_cu = n_cu;
         int G = 1;
         const char *force = getenv("MESHENV_GROUP");
         int want = 1;
         if (force) want = atoi(force);
-        else if (n_envs <= 256 * 16) {
+        else if (n_envs <= n_cu * 16) {
             int g = 1;
-            while (g * 2 <= n_envs / 256 && g * 2 <= 16) g *= 2;
+            while (g * 2 <= n_envs / n_cu && g * 2 <= 16) g *= 2;
             want = g >= 8 ? g : 1;
         }
         for (int g : {16, 8, 4})
             if (g <= want && group_lds_bytes(cap, g) <= 150 * 1024) { G = g; break; }
-        if (!force && (G < 8 || n_envs > 256 * G)) G = 1;  // LDS forced a smaller group: more than one workgroup per CU
+        if (!force && (G < 8 || n_envs > n_cu * G)) G = 1;  // LDS forced a smaller group: more than one workgroup per CU
         MeshEnvParams def;
         meshenv_default_params(&def);
         h->default_params = prm.radius == def.radius && prm.max_ref_angle == def.max_ref_angle && prm.key_lambda == def.key_lambda &&
@@ -319,7 +347,7 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
 int meshenv_set_stream(MeshEnv *h, void *stream)
 {
     if (!h) return MESHENV_E_ARG;
-    HIP_TRY(h, hipSetDevice(h->device));
+    MESHENV_ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->stream = (hipStream_t)stream;
     return MESHENV_OK;
@@ -339,6 +367,7 @@ int meshenv_group_size(const MeshEnv *h) { return h ? h->group : MESHENV_E_ARG; 
 int meshenv_reset(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev)
 {
     if (!h) return MESHENV_E_ARG;
+    MESHENV_ON_DEVICE(h);
     hipLaunchKernelGGL(k_reset, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, mask_dev, obs_dev, 0,
                        (unsigned long long)h->steps_done);
     HIP_TRY(h, hipGetLastError());
@@ -351,6 +380,7 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
     if (!h) return MESHENV_E_ARG;
     if (!actions_dev || !obs_dev || !reward_dev || !done_dev || !complete_dev) return fail_arg(h, "meshenv_step: null device pointer");
     if (n_steps <= 0) return fail_arg(h, "meshenv_rollout: n_steps must be positive");
+    MESHENV_ON_DEVICE(h);
     const size_t slot = (size_t)(h->ev_count % MESHENV_TIMING_POOL);
     const long long pos = h->timing > 0 ? (h->launch_count++ % (2LL * h->timing)) : -1;
     if (pos == 0) HIP_TRY(h, hipEventRecord(h->ev[2 * slot], h->stream));
@@ -412,6 +442,7 @@ __global__ void k_status(DevState S, uint8_t *out)
 int meshenv_get_status(MeshEnv *h, uint8_t *status_dev)
 {
     if (!h || !status_dev) return MESHENV_E_ARG;
+    MESHENV_ON_DEVICE(h);
     hipLaunchKernelGGL(k_status, dim3((h->n_envs + 255) / 256), dim3(256), 0, h->stream, h->S, status_dev);
     HIP_TRY(h, hipGetLastError());
     return MESHENV_OK;
@@ -425,7 +456,7 @@ int meshenv_get_state(MeshEnv *h, int env, int32_t *ring_ids_host, double *ring_
         h->err = "meshenv_get_state: env out of range";
         return MESHENV_E_RANGE;
     }
-    HIP_TRY(h, hipSetDevice(h->device));
+    MESHENV_ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     EnvScalars s;
     HIP_TRY(h, hipMemcpy(&s, h->S.scal + env, sizeof(s), hipMemcpyDeviceToHost));
@@ -480,7 +511,7 @@ static int fetch_elements(MeshEnv *h, const char *fn, int which, int env, int32_
         h->err = std::string(fn) + ": handle was created with log_capacity = 0";
         return MESHENV_E_STATE;
     }
-    HIP_TRY(h, hipSetDevice(h->device));
+    MESHENV_ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     EnvScalars s;
     HIP_TRY(h, hipMemcpy(&s, h->S.scal + env, sizeof(s), hipMemcpyDeviceToHost));
@@ -537,7 +568,7 @@ int meshenv_element_quality(MeshEnv *h, int which, double *elem_dev, double *sta
         h->err = "meshenv_element_quality: handle was created with log_capacity = 0";
         return MESHENV_E_STATE;
     }
-    HIP_TRY(h, hipSetDevice(h->device));
+    MESHENV_ON_DEVICE(h);
     hipLaunchKernelGGL(k_element_quality, dim3(h->n_envs), dim3(64), 0, h->stream, h->S, which, elem_dev, stats_dev,
                        count_dev);
     HIP_TRY(h, hipGetLastError());
@@ -547,7 +578,7 @@ int meshenv_element_quality(MeshEnv *h, int which, double *elem_dev, double *sta
 int meshenv_counters(MeshEnv *h, uint64_t *out_host)
 {
     if (!h || !out_host) return MESHENV_E_ARG;
-    HIP_TRY(h, hipSetDevice(h->device));
+    MESHENV_ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::vector<EnvCounters> c((size_t)h->n_envs);
     std::vector<EnvScalars> sc((size_t)h->n_envs);
@@ -605,7 +636,8 @@ __global__ void k_selftest(int what, int n, const double *in, double *out)
 int meshenv_selftest(int device, int what, int n, int in_per_item, const double *in_host, double *out_host)
 {
     if (n <= 0 || !in_host || !out_host || in_per_item <= 0) return MESHENV_E_ARG;
-    if (hipSetDevice(device) != hipSuccess) return MESHENV_E_HIP;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return MESHENV_E_HIP;
     double *din = nullptr, *dout = nullptr;
     if (hipMalloc(&din, sizeof(double) * (size_t)n * in_per_item) != hipSuccess) return MESHENV_E_HIP;
     if (hipMalloc(&dout, sizeof(double) * (size_t)n) != hipSuccess) { (void)hipFree(din); return MESHENV_E_HIP; }
@@ -624,7 +656,7 @@ int meshenv_selftest(int device, int what, int n, int in_per_item, const double 
 int meshenv_set_timing(MeshEnv *h, int enable)
 {
     if (!h) return MESHENV_E_ARG;
-    HIP_TRY(h, hipSetDevice(h->device));
+    MESHENV_ON_DEVICE(h);
     if (enable && h->ev.empty()) {
         h->ev.resize(2 * (size_t)MESHENV_TIMING_POOL, nullptr);
         for (hipEvent_t &e : h->ev) HIP_TRY(h, hipEventCreate(&e));
@@ -638,7 +670,7 @@ int meshenv_set_timing(MeshEnv *h, int enable)
 int meshenv_kernel_times(MeshEnv *h, float *ms_host, int cap, int32_t *n_out)
 {
     if (!h || !ms_host || !n_out || cap < 0) return MESHENV_E_ARG;
-    HIP_TRY(h, hipSetDevice(h->device));
+    MESHENV_ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     long long have = h->ev_count < MESHENV_TIMING_POOL ? h->ev_count : MESHENV_TIMING_POOL;
     if (have > cap) have = cap;
@@ -677,7 +709,8 @@ int meshenv_actor_create(int device, void *stream, MeshActor **out)
     a->device = device;
     a->stream = (hipStream_t)stream;
     a->nfloat = (size_t)kActInPad * kActHid + kActHid + 2 * ((size_t)kActHid * kActHid + kActHid) + (size_t)kActHid * 16 + 16;
-    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&a->buf, a->nfloat * sizeof(float)) != hipSuccess) {
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess || hipMalloc((void **)&a->buf, a->nfloat * sizeof(float)) != hipSuccess) {
         g_create_error = "meshenv_actor_create: hipMalloc failed";
         delete a;
         return MESHENV_E_HIP;
@@ -689,7 +722,7 @@ int meshenv_actor_create(int device, void *stream, MeshActor **out)
 void meshenv_actor_destroy(MeshActor *a)
 {
     if (!a) return;
-    (void)hipSetDevice(a->device);
+    DeviceGuard guard(a->device);
     (void)hipStreamSynchronize(a->stream);
     if (a->buf) (void)hipFree(a->buf);
     delete a;
@@ -755,7 +788,8 @@ int meshenv_actor_load(MeshActor *a, const float *w1, const float *b1, const flo
         a->err = "meshenv_actor_load: internal size mismatch";
         return MESHENV_E_STATE;
     }
-    if (hipSetDevice(a->device) != hipSuccess ||
+    DeviceGuard guard(a->device);
+    if (guard.err != hipSuccess ||
         hipMemcpy(a->buf, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         a->err = "meshenv_actor_load: upload failed";
         return MESHENV_E_HIP;
@@ -777,7 +811,8 @@ static int actor_launch(MeshActor *a, const char *fn, int n, const float *obs_de
         a->err = std::string(fn) + ": no weights loaded";
         return MESHENV_E_STATE;
     }
-    if (hipSetDevice(a->device) != hipSuccess) {
+    DeviceGuard guard(a->device);
+    if (guard.err != hipSuccess) {
         a->err = std::string(fn) + ": hipSetDevice failed";
         return MESHENV_E_HIP;
     }

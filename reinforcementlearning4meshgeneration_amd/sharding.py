@@ -49,3 +49,72 @@ def gather_messages(dist, msg, gathered=None, group=None):
         gathered = torch.empty((world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=msg.device)
     dist.all_gather_into_tensor(gathered, msg, group=group)
     return gathered
+
+
+class BucketExchange:
+    """The per-step exchange of the multi-GPU path, off the per-step critical path.
+
+    The step kernel writes the [n, 21] message of step t straight into slot ``t % steps`` of a ``[steps, n, 21]``
+    bucket (``slot(t)`` is the tensor to hand to ``MeshVecEnv.set_packed_output`` before launching step t); when the
+    last slot of a bucket has been launched, ``after_step(t)`` issues ONE ``all_gather_into_tensor`` for the whole
+    bucket (asynchronous: RCCL runs it on its own stream, ordered after the launch stream's work at the time of the
+    call) and the next bucket's steps proceed meanwhile.  Two buckets: bucket b is rewritten only after ``wait()`` on the
+    collective that last read it (a stream-level wait for RCCL, a host wait for gloo).  ``consumer(gathered, t0)``, if
+    given, is called with the rank-major ``[world * steps, n, 21]`` result of the bucket whose first step is t0 once
+    that collective has been waited for -- the learner's replay-buffer append.
+
+    ``stage_to_cpu``: the gloo rehearsal on a GPU box (gloo cannot read device memory): the bucket is copied to the host
+    and gathered synchronously.
+    """
+
+    def __init__(self, dist, torch, n_envs: int, steps: int, device, stage_to_cpu: bool = False, consumer=None,
+                 group=None):
+        self.dist, self.torch, self.group = dist, torch, group
+        self.steps = max(1, int(steps))
+        self.world = dist.get_world_size(group)
+        self.stage_to_cpu = bool(stage_to_cpu)
+        self.consumer = consumer
+        gdev = torch.device("cpu") if stage_to_cpu else device
+        self.buckets = [torch.zeros((self.steps, n_envs, MSG_DIM), dtype=torch.float32, device=device) for _ in range(2)]
+        self.gathered = [torch.empty((self.world * self.steps, n_envs, MSG_DIM), dtype=torch.float32, device=gdev)
+                         for _ in range(2)]
+        self.works = [None, None]      # in-flight collective per bucket
+        self.first_step = [None, None]  # first step of the bucket contents handed to that collective
+        self.collectives = 0
+
+    def _bucket(self, t: int) -> int:
+        return (t // self.steps) & 1
+
+    def _retire(self, b: int):
+        if self.works[b] is not None:
+            self.works[b].wait()
+            self.works[b] = None
+        if self.first_step[b] is not None:
+            if self.consumer is not None:
+                self.consumer(self.gathered[b], self.first_step[b])
+            self.first_step[b] = None
+
+    def slot(self, t: int):
+        """Message buffer of step t.  Entering a bucket first retires the collective that last read it."""
+        b, k = self._bucket(t), t % self.steps
+        if k == 0:
+            self._retire(b)
+        return self.buckets[b][k]
+
+    def after_step(self, t: int):
+        b, k = self._bucket(t), t % self.steps
+        if k != self.steps - 1:
+            return
+        if self.stage_to_cpu:
+            self.dist.all_gather_into_tensor(self.gathered[b], self.buckets[b].cpu(), group=self.group)
+        else:
+            self.works[b] = self.dist.all_gather_into_tensor(self.gathered[b], self.buckets[b], group=self.group,
+                                                             async_op=True)
+        self.first_step[b] = t - k
+        self.collectives += 1
+
+    def drain(self):
+        """Wait for everything in flight (oldest bucket first).  A partially filled bucket is not sent."""
+        order = sorted((b for b in (0, 1) if self.first_step[b] is not None), key=lambda b: self.first_step[b])
+        for b in order:
+            self._retire(b)

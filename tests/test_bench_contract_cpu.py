@@ -1,8 +1,11 @@
 """CPU: the bench.py output contract, checked on the committed line of the round (profiles/r01_bench_line.json) and on
 bench.py's own argument defaults -- the driver parses exactly these keys."""
+import importlib.util
 import json
 import os
 import re
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -35,3 +38,48 @@ def test_bench_defaults_finish_in_minutes_and_never_touch_the_reference():
     assert re.search(r'"--gpus", type=int, default=1', src)
     assert re.search(r'"--steps", type=int, default=\d{2,3}\b', src) and re.search(r'"--warmup", type=int, default=\d{1,2}\b', src)
     assert "/root/reference" not in src
+
+
+def _load_bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _closed_groups(n_launches, k):
+    """Model of launch_step's bracketing (csrc/meshenv_hip.hip): launch i has pos = i % 2k; an event pair opens at
+    pos == 0 and closes at pos == k - 1."""
+    closed, open_ = 0, False
+    for i in range(n_launches):
+        pos = i % (2 * k)
+        if pos == 0:
+            open_ = True
+        if pos == k - 1 and open_:
+            closed, open_ = closed + 1, False
+    return closed
+
+
+@pytest.mark.parametrize("steps,warmup", [(20, 5), (1, 0), (200, 20), (2, 0), (30, 5), (49, 1), (1000, 0)])
+def test_every_step_count_closes_a_timing_group(steps, warmup):
+    """The driver's --steps 20 run of round 1 recorded no event group (group size 25 > 20) and lost its roofline."""
+    bench = _load_bench()
+    k = bench.timing_group(steps, 25)
+    assert 1 <= k <= min(25, steps)
+    assert _closed_groups(steps, k) >= 1
+
+
+def test_roofline_is_unconditional_and_labels_follow_the_arguments():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'out["roofline"] = {' in src and "if kt is not None and len(kt):\n        alg" not in src
+    assert '"timing": timing' in src and "wall (no HIP-event group recorded)" in src
+    assert "cpu_model" in src and "fp64_transcendentals_per_env_step" in src and "instruction_side" in src
+    assert 'coll = "RCCL" if args.backend == "nccl" else args.backend' in src
+    assert "N_envs={n} per GPU" in src  # the metric string names the envs / workload actually run
+
+
+def test_algorithmic_bytes_formula_matches_survey_8d():
+    bench = _load_bench()
+    # one failed step on a 30-ring: 28 * 30 + 158; one valid: + 28 * 30 + 48
+    assert bench.algorithmic_bytes(1, 0, 30, 0) == 28 * 30 + 158
+    assert bench.algorithmic_bytes(1, 1, 30, 30) == 56 * 30 + 206

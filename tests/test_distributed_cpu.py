@@ -59,3 +59,64 @@ def test_gather_world_size_2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py's N > 1 schedule: sharding.BucketExchange (two [GS, n, 21] buckets, one async all_gather per bucket) driven
+# by a fake step kernel that writes a recognisable message into the slot it is handed.
+
+def _bucket_worker(rank, world, port, n, GS, T, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from reinforcementlearning4meshgeneration_amd import sharding
+
+    def message(r, t):  # what rank r's step kernel writes at step t
+        base = torch.arange(n, dtype=torch.float32)[:, None] * 1000 + torch.arange(sharding.MSG_DIM, dtype=torch.float32)[None, :]
+        return base + 1e6 * r + 1e5 * (t % 7) + t
+
+    seen, errors = [], []
+
+    def consumer(gathered, t0):
+        seen.append(t0)
+        g = gathered.view(world, GS, n, sharding.MSG_DIM)
+        for r in range(world):
+            for k in range(GS):
+                if not torch.equal(g[r, k], message(r, t0 + k)):
+                    errors.append((t0, r, k))
+
+    xch = sharding.BucketExchange(dist, torch, n, GS, torch.device("cpu"), consumer=consumer)
+    in_flight_max = 0
+    for t in range(T):
+        slot = xch.slot(t)
+        # a bucket may only be rewritten once the collective that read it has been retired
+        assert xch.works[(t // GS) & 1] is None and xch.first_step[(t // GS) & 1] is None
+        slot.copy_(message(rank, t))        # the "kernel"
+        xch.after_step(t)
+        in_flight_max = max(in_flight_max, sum(w is not None for w in xch.works))
+    xch.drain()
+    full = T // GS
+    ok = (not errors and seen == [GS * i for i in range(full)] and xch.collectives == full
+          and all(w is None for w in xch.works) and in_flight_max >= 1)
+    q.put((rank, ok, len(errors), seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("GS,T", [(8, 40), (3, 20), (1, 5)])
+def test_bucket_exchange_schedule_world_size_2(GS, T):
+    """Every gathered bucket holds exactly what both ranks wrote, in step order; buckets are consumed oldest first; no
+    bucket is handed out again before its collective was waited for; a trailing partial bucket is not sent."""
+    world, n = 2, 16
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, n, GS, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, n_err, seen in results:
+        assert ok, (rank, n_err, seen)

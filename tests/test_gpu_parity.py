@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN_DIR, golden_names
+from lockstep import run_lockstep as _run_lockstep  # shared with test_gpu_configs.py
 
 pytestmark = pytest.mark.gpu
 
@@ -84,71 +85,6 @@ def test_hip_matches_reference_trace(torch_cuda, name):
             env.reset()
     env.close()
     print(f"{name}: max obs err {max_obs_err:.3g}, max reward err {max_rew_err:.3g}")
-
-
-def _run_lockstep(torch, domains, env_domain, actions, check_every=64, sample=64, rollout=False):
-    """Step the HIP env and the CPU oracle on the same [T,n,3] actions; compare everything."""
-    from oracle.ref_lib import RefBatch, RefEnv
-    from reinforcementlearning4meshgeneration_amd.vec_env import MeshVecEnv
-
-    n = len(env_domain)
-    T = actions.shape[0]
-    env = MeshVecEnv(domains, env_domain=env_domain, auto_reset=True, log_capacity=0)
-    consts = env.constants
-    refs = [RefEnv(np.asarray(domains[d], np.float64), consts[d].original_area, consts[d].est_min_l,
-                   consts[d].est_crit_l, cap_new=64) for d in env_domain]
-    batch = RefBatch(refs)
-    obs_ref = batch.reset().copy()
-    obs = env.reset().cpu().numpy()
-    np.testing.assert_array_equal(obs, obs_ref)
-    acts_dev = torch.from_numpy(actions).cuda()
-    stats = dict(obs_mismatch=0, obs_total=0, max_obs=0.0, max_rew=0.0, valid=0, done=0)
-    if rollout:
-        _, rew_all, done_all, comp_all = env.rollout(acts_dev)
-        rew_all = rew_all.cpu().numpy(); done_all = done_all.cpu().numpy(); comp_all = comp_all.cpu().numpy()
-    rng = np.random.default_rng(0)
-    sum_ring = 0
-    for t in range(T):
-        if n <= 512:   # the lazily kept sum of ring lengths over all steps (roofline accounting) against the oracle
-            sum_ring += sum(r.L.meshenv_ref_ring_len(r.h) for r in refs)
-        o_ref, r_ref, d_ref, c_ref = batch.step(actions[t], auto_reset=True, threads=8)
-        if rollout:
-            r, d, c = rew_all[t], done_all[t], comp_all[t]
-        else:
-            o, r, d, c = env.step(acts_dev[t])
-            o = o.cpu().numpy(); r = r.cpu().numpy(); d = d.cpu().numpy(); c = c.cpu().numpy()
-            diff = np.abs(o.astype(np.float64) - o_ref)
-            stats["obs_mismatch"] += int((o != o_ref).sum())
-            stats["obs_total"] += o.size
-            stats["max_obs"] = max(stats["max_obs"], float(diff.max()))
-            assert diff.max() <= TOL, (t, np.unravel_index(diff.argmax(), diff.shape))
-        np.testing.assert_array_equal(d, d_ref, err_msg=f"done step {t}")
-        np.testing.assert_array_equal(c, c_ref, err_msg=f"complete step {t}")
-        rerr = float(np.abs(r - r_ref).max())
-        stats["max_rew"] = max(stats["max_rew"], rerr)
-        assert rerr <= TOL, (t, int(np.abs(r - r_ref).argmax()))
-        stats["done"] += int(d_ref.sum())
-        if not rollout and (t % check_every == check_every - 1 or t == T - 1):
-            for k in rng.choice(n, size=min(sample, n), replace=False):
-                st = env.get_state(int(k))
-                ids, xy = refs[k].ring()
-                np.testing.assert_array_equal(st["ring_ids"], ids, err_msg=f"ring env {k} step {t}")
-                np.testing.assert_array_equal(st["ring_xy"], xy, err_msg=f"ring xy env {k} step {t}")
-                cid, ckey = refs[k].candidates()
-                np.testing.assert_array_equal(st["cand_order_ids"], cid, err_msg=f"cand env {k} step {t}")
-                sc = refs[k].scalars()
-                assert st["n_elem"] == sc["n_elem"] and st["failed_num"] == sc["failed_num"]
-                assert st["ref_id"] == refs[k].ref_id()
-    if rollout:
-        o = env.obs.cpu().numpy()
-        assert np.abs(o.astype(np.float64) - batch.obs).max() <= TOL
-    cnt = env.counters()
-    stats["valid"] = cnt["valid"]
-    assert cnt["steps"] == T * n
-    if n <= 512:
-        assert cnt["sum_ring"] == sum_ring, (cnt, sum_ring)
-    env.close()
-    return stats
 
 
 def test_config2_4096_boundary_envs_step_parity(torch_cuda):

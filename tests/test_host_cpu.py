@@ -138,3 +138,26 @@ def test_helper_placement_table_of_the_group_kernel():
                         helpers.append(below + t)
             assert sorted(mains) == list(range(m)), (G, m, mains)
             assert sorted(helpers) == list(range(m)), (G, m, helpers)
+
+
+def test_every_hip_entry_point_runs_on_the_handles_device_and_restores_the_callers():
+    """A process may hold handles on several GPUs: each C-ABI function that launches, copies or synchronises must switch
+    to the handle's device through the save/restore guard, never through a bare hipSetDevice (which would leave the
+    caller's -- torch's -- current device changed).  Checked on the source: a one-GPU box cannot show a wrong device."""
+    src = open(os.path.join(ROOT, "reinforcementlearning4meshgeneration_amd", "csrc", "meshenv_hip.hip")).read()
+    body = src[src.index('extern "C" {'):]
+    bare = [m.start() for m in re.finditer(r"hipSetDevice\(", body)]
+    assert not bare, "bare hipSetDevice in an entry point: use DeviceGuard / MESHENV_ON_DEVICE"
+    # split into top-level function bodies and check those that touch the runtime
+    funcs = re.split(r"\n(?=(?:static\s+)?(?:int|void|const char \*)\s+\*?[a-z_]+\()", body)
+    needs = re.compile(r"hipLaunchKernelGGL|hipMemcpy|hipStreamSynchronize|hipEventRecord|hipEventCreate|hipMalloc\(|hipFree\(|hipDeviceSynchronize")
+    checked = 0
+    for f in funcs:
+        name = re.match(r"(?:static\s+)?(?:int|void|const char \*)\s+\*?([a-z_0-9]+)\(", f)
+        if not name or not needs.search(f) or "MESHENV_STAMPS" in f.split("{", 1)[0]:
+            continue
+        if name.group(1).startswith("meshenv_debug_"):
+            continue
+        assert re.search(r"MESHENV_ON_DEVICE\(|DeviceGuard\s+guard\(", f), f"{name.group(1)} has no device guard"
+        checked += 1
+    assert checked >= 12
