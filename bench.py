@@ -153,6 +153,8 @@ def main():
                          "configs[2] domain); mixed = d1/d2/d3 interleaved (configs[3] shape); random = one "
                          "GenerateRandomPolygon-style ring per env (configs[4] shape).  Domain coordinates of d1/d2/d3 "
                          "come from tests/golden (data recorded from the reference's ui/domains files)")
+    ap.add_argument("--preroll", type=int, default=512,
+                    help="untimed steps (fused rollouts) that bring the random policy to its steady state before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-every", type=int, default=8, help="N > 1: steps per all-gather bucket")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
@@ -263,6 +265,18 @@ def main():
             torch.cuda.synchronize()
         scratch.close()
 
+    # Pre-roll (untimed, before the W warm-up steps): the uniform-random policy is brought to its stationary mix of ring
+    # lengths / episode phases with fused rollouts on its own action stream, so that the measured workload does not depend
+    # on how few warm-up steps the caller asks for (fresh envs all sit on the full 30-vertex ring: 15 % valid actions
+    # against 11.7 % in the steady state).
+    if args.preroll > 0:
+        pr = (lo + (hi - lo) * torch.rand((64, n, 3), device=dev, generator=gen)).to(torch.float32).contiguous()
+        for _ in range((args.preroll + 63) // 64):
+            env.rollout(pr)
+            pr = pr.roll(1, dims=1).contiguous()   # a different env/action pairing every round
+        torch.cuda.synchronize()
+        env._bind_stream()
+
     for t in range(W):
         one_step(t)
     drain()
@@ -309,7 +323,7 @@ def main():
                                "uniform-random float32 actions resident in HBM, auto-reset, one meshenv_step launch "
                                "per vector step" + (f", + one async {coll} all-gather per {GS} steps of the [{GS},n,21] f32 obs/reward/done bucket written by the kernel" if do_gather else ""),
                    "n_envs_per_gpu": n, "n_envs_total": n * world, "parallelism": f"env-shard x{world}",
-                   "clock_warmup_ms": args.clock_warmup_ms,
+                   "clock_warmup_ms": args.clock_warmup_ms, "preroll_steps": args.preroll,
                    "valid_action_rate": d["valid"] / max(1, d["steps"]), "mean_ring_len": d["sum_ring"] / max(1, d["steps"])},
     }
     # roofline of the dominant kernel (the one-step kernel): never omitted -- without a closed event group (timing

@@ -183,10 +183,37 @@ def quality_fixture():
 ep_keys = []
 
 
+# move() API fixtures: (fixture name, domain or literal ring, seed, T, reset_on_done)
+HEXAGON = [(0.0, 0.0), (0.0, 1.0), (0.0, 2.0), (1.0, 2.0), (1.0, 1.0), (1.0, 0.0)]
+OCTAGON = [(0.0, 0.0), (0.0, 1.0), (0.0, 2.0), (0.0, 3.0), (1.0, 3.0), (1.0, 2.0), (1.0, 1.0), (1.0, 0.0)]
+HEPTAGON = [(0.0, 0.0), (0.0, 1.0), (0.0, 2.0), (1.0, 2.5), (2.0, 2.0), (2.0, 1.0), (2.0, 0.0)]   # odd ring: ends on 5
+MOVE_TRACES = [
+    ("move_boundary0_s0", "boundary0", 0, 700, True),
+    ("move_boundary16_s1", "boundary16", 1, 300, True),
+    ("move_random1_1_s2", "random1_1", 2, 250, True),
+    ("move_hexagon_s3", HEXAGON, 3, 120, False),     # completes in one or two moves; then the reference raises
+    ("move_octagon_s4", OCTAGON, 4, 200, False),
+    ("move_heptagon_s5", HEPTAGON, 5, 120, False),
+]
+
+
+def main_move():
+    for name, dom, seed, T, reset_on_done in MOVE_TRACES:
+        pts = H.domain_points(dom) if isinstance(dom, str) else dom
+        p, ty = H.move_inputs(seed, T)
+        tr = H.record_move_trace(pts, p, ty, reset_on_done=reset_on_done)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **tr)
+        print(f"{name}: {T} moves, {int(tr['valid'].sum())} valid, codes {np.bincount(tr['code'], minlength=4).tolist()}, "
+              f"done {int(tr['done'].sum())}, complete {int(tr['complete'].sum())}, max not_valid {int(tr['n_not_valid'].max())}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--quality-only" in sys.argv:
         quality_fixture()
+        return
+    if "--move-only" in sys.argv:
+        main_move()
         return
     export_fixture()
     quality_fixture()
@@ -196,6 +223,7 @@ def main():
         save(name, H.record_trace(pts, acts))
     pts, acts = targeted_trace()
     save("boundary0_targeted", H.record_trace(pts, acts))
+    main_move()
 
 
 if __name__ == "__main__":

@@ -67,6 +67,9 @@ struct RefEnv {
     /* domain */
     P2 *ring0;
     double orig_area, min_l, crit_l;
+    /* move() API: not_valid_points (B:47, reference points of rejected moves; matched by distance < 0.001, M:428-433) */
+    P2 *nv;
+    int n_nv;
     /* logs */
     int cap_v, cap_e;
     P2 *vtab;
@@ -207,12 +210,22 @@ static void add_candidate(RefEnv *e, int pos)
     }
 }
 
-/* find_reference_point, M:295-316: list head */
-static int select_reference(const RefEnv *e)
+/* is_vertex_inside_list, M:428-433 */
+static int in_not_valid(const RefEnv *e, P2 v)
+{
+    for (int k = 0; k < e->n_nv; k++)
+        if (dist(e->nv[k], v) < 0.001) return 1;
+    return 0;
+}
+
+/* find_reference_point, M:295-316: list head; with not_valid_points (use_nv, the move() API) the first list entry that
+ * is not within 0.001 of one of them */
+static int select_reference_nv(const RefEnv *e, int use_nv)
 {
     int best = -1;
     for (int i = 0; i < e->n; i++) {
         if (!e->cand[i]) continue;
+        if (use_nv && e->n_nv > 0 && in_not_valid(e, e->ring[i])) continue;
         if (best < 0 || e->key[i] < e->key[best] ||
             (e->key[i] == e->key[best] && e->stamp[i] > e->stamp[best]))
             best = i;
@@ -224,9 +237,12 @@ static int select_reference(const RefEnv *e)
 
 /* PointEnvironment.get_neighbors + get_radius_points, C:1081-1090, 1192-1290;
  * find_next_state, B:521-588 */
-static int find_next_state(RefEnv *e, float *obs)
+static int find_next_state_opt(RefEnv *e, float *obs, int is_static, int use_nv);
+
+/* is_static: PointEnvironment(static=True), C:1213-1218 -- row 0 carries 0 instead of the area ratio */
+static int find_next_state_opt(RefEnv *e, float *obs, int is_static, int use_nv)
 {
-    e->ref = select_reference(e);
+    e->ref = select_reference_nv(e, use_nv);
     if (e->ref < 0) {
         memset(obs, 0, 18 * sizeof(float));
         return 1;
@@ -253,7 +269,7 @@ static int find_next_state(RefEnv *e, float *obs)
     for (int i = 0; i < 9; i++) r[i][0] = r[i][1] = 1.0f;
 
     r[0][0] = (float)((dist(ref, right) / 4) / bl);
-    r[0][1] = (float)area_ratio;
+    r[0][1] = is_static ? 0.0f : (float)area_ratio;
     r[8][0] = (float)((dist(ref, left) / 4) / bl);
     r[8][1] = (float)theta;
     for (int i = 1; i < 3; i++) {
@@ -572,6 +588,46 @@ static void log_quad(RefEnv *e, const int32_t *ids)
     e->n_elem += 1;
 }
 
+/* generated_meshes.append (B:209) + update_boundary (M:601-669) + the candidate list patch, shared by step() and move().
+ * Returns the boundary-quality term of the reward (computed on the post-update ring) when want_reward, else 0. */
+static double extract_element(RefEnv *e, const P2 *m, const int *mpos, int new_vertex, int index, P2 new_point,
+                              int want_reward)
+{
+    const int n = e->n;
+    (void)m;
+    int32_t qids[4];
+    for (int k = 0; k < 4; k++) qids[k] = mpos[k] < 0 ? e->n_vert : e->rid[mpos[k]];
+    log_quad(e, qids); /* generated_meshes.append, B:209 */
+
+    /* update_boundary, M:601-669 */
+    double b_reward = 0.0;
+    if (new_vertex) {
+        const int id = index;
+        e->ring[id] = new_point;
+        e->rid[id] = e->n_vert;
+        e->cand[id] = 0;
+        if (e->n_vert < e->cap_v) e->vtab[e->n_vert] = new_point;
+        e->n_vert += 1;
+        int pos[4] = {(id + 1) % n, RI(id - 1, n), (id + 2) % n, RI(id - 2, n)};
+        for (int k = 0; k < 4; k++) e->cand[pos[k]] = 0;
+        for (int k = 0; k < 4; k++) add_candidate(e, pos[k]);
+        if (want_reward) b_reward = boundary_quality_new(e, id);
+    } else {
+        int32_t keep0 = e->rid[mpos[0]], keep1 = e->rid[mpos[3]];
+        int32_t rem0 = e->rid[mpos[1]], rem1 = e->rid[mpos[2]];
+        ring_delete(e, ring_find(e, rem0));
+        ring_delete(e, ring_find(e, rem1));
+        const int nn = e->n;
+        int t0 = ring_find(e, keep0), t1 = ring_find(e, keep1);
+        int id = t0 > t1 ? t0 : t1;
+        int pos[4] = {id % nn, RI(id - 1, nn), (id + 1) % nn, RI(id - 2, nn)};
+        for (int k = 0; k < 4; k++) e->cand[pos[k]] = 0;
+        for (int k = 0; k < 4; k++) add_candidate(e, pos[k]);
+        if (want_reward) b_reward = boundary_quality_kept(e, t0, t1);
+    }
+    return b_reward;
+}
+
 /* ---------------------------------------------------------------- API */
 
 RefEnv *meshenv_ref_create(int n0, const double *xy, double original_area, double est_min_l,
@@ -585,6 +641,8 @@ RefEnv *meshenv_ref_create(int n0, const double *xy, double original_area, doubl
     e->cand = (uint8_t *)malloc(n0);
     e->key = (double *)malloc(sizeof(double) * n0);
     e->stamp = (int64_t *)malloc(sizeof(int64_t) * n0);
+    e->nv = (P2 *)malloc(sizeof(P2) * (size_t)(n0 + 8));
+    e->n_nv = 0;
     for (int i = 0; i < n0; i++) {
         e->ring0[i].x = xy[2 * i];
         e->ring0[i].y = xy[2 * i + 1];
@@ -605,11 +663,13 @@ void meshenv_ref_destroy(RefEnv *e)
 {
     if (!e) return;
     free(e->ring); free(e->ring0); free(e->rid); free(e->cand); free(e->key); free(e->stamp);
-    free(e->vtab); free(e->quads); free(e);
+    free(e->vtab); free(e->quads); free(e->nv); free(e);
 }
 
 /* B:84-101 */
-int meshenv_ref_reset(RefEnv *e, float *obs)
+int meshenv_ref_reset(RefEnv *e, float *obs) { return meshenv_ref_reset_static(e, obs, 0); }
+
+int meshenv_ref_reset_static(RefEnv *e, float *obs, int is_static)
 {
     e->n = e->n0;
     for (int i = 0; i < e->n0; i++) {
@@ -621,8 +681,9 @@ int meshenv_ref_reset(RefEnv *e, float *obs)
     e->n_elem = 0;
     e->failed = 0;
     e->cur_area = e->orig_area;
+    e->n_nv = 0; /* self.not_valid_points = [], B:90 */
     find_reference_candidates(e);
-    return find_next_state(e, obs);
+    return find_next_state_opt(e, obs, is_static, 0);
 }
 
 /* B:130-280 */
@@ -701,36 +762,7 @@ int meshenv_ref_step(RefEnv *e, const float *action, float *obs, double *reward_
             for (int k = 0; k < 4; k++) m[k] = mpos[k] < 0 ? new_point : e->ring[mpos[k]];
 
             if (quad_is_valid(m) && !intersects_boundary(e, m, mpos, r)) {
-                int32_t qids[4];
-                for (int k = 0; k < 4; k++) qids[k] = mpos[k] < 0 ? e->n_vert : e->rid[mpos[k]];
-                log_quad(e, qids); /* generated_meshes.append, B:209 */
-
-                /* update_boundary, M:601-669 */
-                double b_reward;
-                if (new_vertex) {
-                    const int id = index;
-                    e->ring[id] = new_point;
-                    e->rid[id] = e->n_vert;
-                    e->cand[id] = 0;
-                    if (e->n_vert < e->cap_v) e->vtab[e->n_vert] = new_point;
-                    e->n_vert += 1;
-                    int pos[4] = {(id + 1) % n, RI(id - 1, n), (id + 2) % n, RI(id - 2, n)};
-                    for (int k = 0; k < 4; k++) e->cand[pos[k]] = 0;
-                    for (int k = 0; k < 4; k++) add_candidate(e, pos[k]);
-                    b_reward = boundary_quality_new(e, id);
-                } else {
-                    int32_t keep0 = e->rid[mpos[0]], keep1 = e->rid[mpos[3]];
-                    int32_t rem0 = e->rid[mpos[1]], rem1 = e->rid[mpos[2]];
-                    ring_delete(e, ring_find(e, rem0));
-                    ring_delete(e, ring_find(e, rem1));
-                    const int nn = e->n;
-                    int t0 = ring_find(e, keep0), t1 = ring_find(e, keep1);
-                    int id = t0 > t1 ? t0 : t1;
-                    int pos[4] = {id % nn, RI(id - 1, nn), (id + 1) % nn, RI(id - 2, nn)};
-                    for (int k = 0; k < 4; k++) e->cand[pos[k]] = 0;
-                    for (int k = 0; k < 4; k++) add_candidate(e, pos[k]);
-                    b_reward = boundary_quality_kept(e, t0, t1);
-                }
+                const double b_reward = extract_element(e, m, mpos, new_vertex, index, new_point, 1);
                 const double mesh_area = quad_area(m);
                 e->cur_area -= mesh_area;
                 /* get_quality(mesh, 2), M:1759-1766 */
@@ -749,7 +781,7 @@ int meshenv_ref_step(RefEnv *e, const float *action, float *obs, double *reward_
         }
     }
     int is_complete = no_reference ? 0 : 1;
-    int none = find_next_state(e, obs);
+    int none = find_next_state_opt(e, obs, 0, 1); /* B:267: find_next_state(self.not_valid_points, ...) */
     if (!failed) {
         e->failed = 0;
     } else {
@@ -764,6 +796,104 @@ int meshenv_ref_step(RefEnv *e, const float *action, float *obs, double *reward_
     *complete_out = (uint8_t)is_complete;
     return none;
 }
+
+
+/* round(python_float, 6): correctly-rounded decimal rounding, as round4_py with scale 1e6 */
+static double round6_py(double x)
+{
+    if (!isfinite(x)) return x;
+    double ax = fabs(x);
+    double y = ax * 1e6;
+    if (y >= 4503599627370496.0) return x;
+    double er = fma(ax, 1e6, -y); /* exact: ax*1e6 == y + er */
+    double f = floor(y);
+    double t = (y - f) - 0.5;
+    double s = t + er;
+    double r;
+    if (s > 0) r = f + 1;
+    else if (s < 0) r = f;
+    else r = (fmod(f, 2.0) == 0.0) ? f : f + 1;
+    return copysign(r / 1e6, x);
+}
+
+/* move(new_point, type), B:282-449, for Python-float arguments: new_point = (radius fraction, angle), `type` the rule
+ * selector with TYPE_THRESHOLD = 0.3 (B:19).  No reward (the reference returns 0), no current_area / failed_num
+ * bookkeeping; rejected reference vertices accumulate in not_valid_points and are skipped by the next selection; the
+ * observation is the static one.
+ * Returns MESHENV_REF_MOVE_*: OK, NONE (obs is None; only possible with ring <= 4 here), RAISES (ring <= 5 on entry:
+ * the reference leaves `is_complete` unbound and raises UnboundLocalError; nothing is changed), NEEDS_SMOOTHING (no
+ * reference vertex is left while the ring has more than 4 vertices: the reference runs smooth_pave (M:1100-1392, not
+ * built) and retries; here the move ends the episode as not complete). */
+int meshenv_ref_move(RefEnv *e, const double *point, double type, float *obs, uint8_t *done_out, uint8_t *complete_out)
+{
+    if (e->n <= 5 || e->ref < 0) return MESHENV_REF_MOVE_RAISES;
+    const int n = e->n, index = e->ref;
+    /* B:283-287 */
+    const double x = ((e->bl * 4) * point[0]) * cos(point[1]);
+    const double y = ((e->bl * 4) * point[0]) * sin(point[1]);
+    const double px = round6_py(x), py = round6_py(y);
+    const P2 p0 = e->ring[index], p1 = e->ring[RI(index - 1, n)];
+    const double theta = 2 * PI - atan2(p1.y - p0.y, p1.x - p0.x);
+    double ox = cos(theta) * px + sin(theta) * py;
+    double oy = -sin(theta) * px + cos(theta) * py;
+    ox *= 1; /* is_move: the scale is 1, B:122 */
+    oy *= 1;
+    ox += p0.x;
+    oy += p0.y;
+    const P2 new_point = {round4_np(ox), round4_np(oy)};
+
+    int done = 0, not_valid = 1, none = 0;
+    const P2 reference_point = e->ring[index];
+    P2 m[4];
+    int mpos[4], have_mesh = 1, r = 2, new_vertex = 0;
+    if (type <= 0.3) { /* B:303-310 */
+        mpos[0] = RI(index - 1, n); mpos[1] = index; mpos[2] = (index + 1) % n; mpos[3] = (index + 2) % n;
+        r = 1;
+    } else if (type >= 1 - 0.3) { /* B:312-319 */
+        mpos[0] = RI(index - 2, n); mpos[1] = RI(index - 1, n); mpos[2] = index; mpos[3] = (index + 1) % n;
+    } else if (is_point_inside_area(e, new_point)) { /* B:320-326: no find_same_point here */
+        mpos[0] = -1; mpos[1] = RI(index - 1, n); mpos[2] = index; mpos[3] = (index + 1) % n;
+        new_vertex = 1;
+    } else {
+        have_mesh = 0;
+    }
+    if (have_mesh) {
+        for (int k = 0; k < 4; k++) m[k] = mpos[k] < 0 ? new_point : e->ring[mpos[k]];
+        if (quad_is_valid(m) && !intersects_boundary(e, m, mpos, r)) {
+            not_valid = 0;
+            extract_element(e, m, mpos, new_vertex, index, new_point, 0);
+            none = find_next_state_opt(e, obs, 1, 1); /* B:362, still with the old not_valid_points */
+            if (e->n <= 5) { /* B:364-368 */
+                done = 1;
+                if (e->n == 4) log_quad(e, e->rid);
+            }
+        }
+    }
+    if (not_valid) { /* B:375-378; `reference_point not in list` is object identity: a ring vertex is listed once */
+        int listed = 0;
+        for (int k = 0; k < e->n_nv; k++)
+            if (e->nv[k].x == reference_point.x && e->nv[k].y == reference_point.y) listed = 1;
+        if (!listed) e->nv[e->n_nv++] = reference_point;
+        none = find_next_state_opt(e, obs, 1, 1);
+    } else {
+        e->n_nv = 0; /* B:382 */
+    }
+    int is_complete, rc = none ? MESHENV_REF_MOVE_NONE : MESHENV_REF_MOVE_OK;
+    if (e->n > 4) {
+        is_complete = 0;
+        if (none) { /* B:421-443: smooth_pave + retry in the reference */
+            done = 1;
+            rc = MESHENV_REF_MOVE_NEEDS_SMOOTHING;
+        }
+    } else {
+        is_complete = 1;
+    }
+    *done_out = (uint8_t)done;
+    *complete_out = (uint8_t)is_complete;
+    return rc;
+}
+
+int meshenv_ref_not_valid_count(const RefEnv *e) { return e->n_nv; }
 
 int meshenv_ref_ring_len(const RefEnv *e) { return e->n; }
 

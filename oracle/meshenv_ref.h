@@ -41,6 +41,16 @@ int meshenv_ref_reset(RefEnv *e, float *obs);
 int meshenv_ref_step(RefEnv *e, const float *action, float *obs, double *reward, uint8_t *done,
                      uint8_t *is_complete);
 
+/* reset(static=True), rl/boundary_env.py:67-84 with PointEnvironment(static=True): row 0 of the observation carries 0
+ * instead of the area ratio (general/components.py:1213-1218) */
+int meshenv_ref_reset_static(RefEnv *e, float *obs, int is_static);
+
+/* move(new_point, type), rl/boundary_env.py:265-432 (the deterministic API the ANN / testbed scripts drive), for
+ * Python-float arguments.  point[2] = (radius fraction, angle); see meshenv_ref.c for the return codes. */
+enum { MESHENV_REF_MOVE_OK = 0, MESHENV_REF_MOVE_NONE = 1, MESHENV_REF_MOVE_RAISES = 2, MESHENV_REF_MOVE_NEEDS_SMOOTHING = 3 };
+int meshenv_ref_move(RefEnv *e, const double *point, double type, float *obs, uint8_t *done, uint8_t *is_complete);
+int meshenv_ref_not_valid_count(const RefEnv *e);
+
 /* state readout for parity tests */
 int meshenv_ref_ring_len(const RefEnv *e);
 void meshenv_ref_get_ring(const RefEnv *e, int32_t *ids, double *xy);

@@ -201,3 +201,82 @@ def record_trace(points, actions: np.ndarray, auto_reset: bool = True) -> dict:
         auto_reset=np.uint8(auto_reset),
     )
     return out
+
+
+# ------------------------------------------------------------------------------------------------ move() API
+class _NeedsSmoothing(Exception):
+    """Raised from the patched smooth_pave: the reference would smooth the mesh here (graph-based, not restated)."""
+
+
+def move_inputs(seed: int, T: int):
+    """Python-float (radius fraction, angle) pairs and rule selectors for BoudaryEnv.move (rl/boundary_env.py:265):
+    points in the half plane where valid elements lie, selectors spread over the three branches of TYPE_THRESHOLD."""
+    rng = np.random.default_rng(seed)
+    pts = np.stack([rng.uniform(0.05, 0.45, T), rng.uniform(0.2, 1.5, T)], axis=1)
+    wild = rng.random(T) < 0.15
+    pts[wild] = np.stack([rng.uniform(0.0, 1.2, int(wild.sum())), rng.uniform(-3.2, 3.2, int(wild.sum()))], axis=1)
+    types = rng.uniform(0.0, 1.0, T)
+    edge = rng.random(T) < 0.08            # the threshold values themselves
+    types[edge] = rng.choice([0.3, 0.7, 1 - 0.3, 0.0, 1.0], int(edge.sum()))
+    return pts.astype(np.float64), types.astype(np.float64)
+
+
+def record_move_trace(points, pts: np.ndarray, types: np.ndarray, static_reset: bool = True,
+                      reset_on_done: bool = True) -> dict:
+    """Drive the reference's move() with Python floats and record what parity needs.  A call the reference cannot answer
+    is recorded by its code: 2 = it raises UnboundLocalError (ring <= 5 on entry), 3 = it enters smooth_pave."""
+    env = make_env(points)
+    n0 = len(points)
+    T = len(pts)
+
+    def _patched(*a, **k):
+        raise _NeedsSmoothing()
+    env.smooth_pave = _patched
+
+    def ids_of(vlist):
+        table = {id(v): k for k, v in enumerate(env.boundary.vertices)}
+        return [table[id(v)] for v in vlist]
+
+    reset_obs = env.reset(static=static_reset)
+    out = dict(
+        obs=np.zeros((T, 18), np.float32), code=np.zeros(T, np.uint8), done=np.zeros(T, np.uint8),
+        complete=np.zeros(T, np.uint8), ring_len=np.zeros(T, np.int32), ring_ids=np.full((T, n0), -1, np.int32),
+        ref_id=np.full(T, -1, np.int32), n_elem=np.zeros(T, np.int32), n_not_valid=np.zeros(T, np.int32),
+        new_xy=np.full((T, 2), np.nan, np.float64), valid=np.zeros(T, np.uint8), was_reset=np.zeros(T, np.uint8),
+    )
+    for t in range(T):
+        nverts_before = len(env.boundary.vertices)
+        nelem_before = len(env.generated_meshes)
+        try:
+            obs, rew, done, info = env.move([float(pts[t, 0]), float(pts[t, 1])], float(types[t]))
+            assert rew == 0
+            code = 1 if obs is None else 0
+            comp = info["is_complete"]
+        except UnboundLocalError:
+            obs, done, comp, code = None, False, False, 2
+        except _NeedsSmoothing:
+            obs, done, comp, code = None, True, False, 3
+        out["code"][t] = code
+        if obs is not None:
+            out["obs"][t] = obs
+        out["done"][t] = done
+        out["complete"][t] = comp
+        ring = ids_of(env.updated_boundary.vertices)
+        out["ring_len"][t] = len(ring)
+        out["ring_ids"][t, :len(ring)] = ring
+        if code == 0:
+            out["ref_id"][t] = ids_of([env.current_point_environment.reference_point])[0]
+        out["n_elem"][t] = len(env.generated_meshes)
+        out["n_not_valid"][t] = len(env.not_valid_points)
+        out["valid"][t] = len(env.generated_meshes) > nelem_before
+        if len(env.boundary.vertices) > nverts_before:
+            v = env.boundary.vertices[-1]
+            out["new_xy"][t] = (v.x, v.y)
+        if (done and reset_on_done) or code >= 2:   # reset_on_done False: the next call on the finished ring raises (code 2)
+            env.reset(static=static_reset)
+            out["was_reset"][t] = 1
+    out.update(domain_xy=np.array(points, np.float64), points=pts, types=types,
+               reset_obs=reset_obs.astype(np.float32), static_reset=np.uint8(static_reset),
+               consts=np.array([float(env.original_area), float(env.average_edge_length),
+                                float(env.estimated_area_range[0]), float(env.estimated_area_range[1])], np.float64))
+    return out

@@ -38,6 +38,12 @@ def lib():
     L.meshenv_ref_destroy.argtypes = [C.c_void_p]
     L.meshenv_ref_reset.restype = C.c_int
     L.meshenv_ref_reset.argtypes = [C.c_void_p, _f32p]
+    L.meshenv_ref_reset_static.restype = C.c_int
+    L.meshenv_ref_reset_static.argtypes = [C.c_void_p, _f32p, C.c_int]
+    L.meshenv_ref_move.restype = C.c_int
+    L.meshenv_ref_move.argtypes = [C.c_void_p, _f64p, C.c_double, _f32p, _u8p, _u8p]
+    L.meshenv_ref_not_valid_count.restype = C.c_int
+    L.meshenv_ref_not_valid_count.argtypes = [C.c_void_p]
     L.meshenv_ref_step.restype = C.c_int
     L.meshenv_ref_step.argtypes = [C.c_void_p, _f32p, _f32p, _f64p, _u8p, _u8p]
     L.meshenv_ref_ring_len.restype = C.c_int
@@ -122,9 +128,20 @@ class RefEnv:
         except Exception:
             pass
 
-    def reset(self):
-        none = self.L.meshenv_ref_reset(self.h, self._obs)
+    def reset(self, static=False):
+        none = self.L.meshenv_ref_reset_static(self.h, self._obs, int(bool(static)))
         return self._obs.copy(), bool(none)
+
+    MOVE_OK, MOVE_NONE, MOVE_RAISES, MOVE_NEEDS_SMOOTHING = 0, 1, 2, 3
+
+    def move(self, point, type_):
+        """move((radius fraction, angle), type) -> (obs, done, is_complete, code); code as MESHENV_REF_MOVE_*."""
+        p = np.ascontiguousarray(point, np.float64).reshape(2)
+        code = self.L.meshenv_ref_move(self.h, p, float(type_), self._obs, self._done, self._comp)
+        return self._obs.copy(), bool(self._done[0]), bool(self._comp[0]), int(code)
+
+    def not_valid_count(self):
+        return int(self.L.meshenv_ref_not_valid_count(self.h))
 
     def step(self, action):
         a = np.ascontiguousarray(action, np.float32)

@@ -6,6 +6,8 @@ Host-side (Python) part of the hot path's input format:
 * ``read_polygon(path)``     -- ui/domains/*.json loader, general/polygon.py:110-117 (first line of the
                                file is ``[[x, y], ...]`` in pixels; coordinates are divided by 100)
 * ``generate_polygon(...)``  -- restatement of ui/GenerateRandomPolygon.py:5-49 (config 5)
+* ``calculate_density`` / ``check_clockwise`` / ``normalise_clockwise`` / ``density_domain`` -- the drawing UI's graded
+                               edge subdivision and orientation rule (ui/tk-ui.py:252-276, 169-176, 84-101)
 * ``domain_constants(pts)``  -- original_area (general/components.py:477-479), average_edge_length
                                (components.py:442-447) and estimate_area_range (general/mesh.py:679-692)
 
@@ -108,42 +110,113 @@ def generate_polygon(ctr_x=250, ctr_y=250, ave_radius=100, irregularity=0.55, sp
     return points
 
 
-def densify(points: Sequence[Point], target: float) -> List[Point]:
-    """Split every edge into equal pieces no longer than ``target`` (the edge densification the
-    drawing UI applies before saving, ui/tk-ui.py:252-276, restated as a pure function)."""
-    out: List[Point] = []
+def clockwise_angle(a: Point, b: Point) -> float:
+    """ui/tk-ui.py:185-192: direction of a -> b as an angle in [0, 2 pi) (screen coordinates: -atan2(-dy, dx))."""
+    theta = -math.atan2(-(b[1] - a[1]), b[0] - a[0])
+    return theta if math.copysign(1, theta) >= 0 else 2 * math.pi + theta
+
+
+def calculate_density(points: Sequence[Point], base_length: float, densities: Sequence[float]) -> List[Point]:
+    """The drawing UI's graded edge subdivision, ui/tk-ui.py:252-276 (Density.calculate_density), as a pure function.
+
+    Every vertex carries a density; on the edge prev -> k the spacing grows from A = density(prev) * base_length to
+    B = density(k) * base_length in an arithmetic progression: x = round((2L - A - B) / (A + B)) interior points
+    (Python's round: half to even), increment e = (B - A) / x, cumulative offsets A (j + 1) + e (j*j + j) / 2, then the
+    edge length L itself; the points are prev + offset * (cos, sin)(clockwise_angle(prev, k)).  The first edge is
+    (last vertex -> vertex 0).  On the last edge one middle point is dropped if that makes the total EVEN (a quad front
+    closes on a 4-ring only with an even vertex count).  Like the reference this raises ZeroDivisionError when an edge
+    gets x == 0 (its length within [0.5, 1.5] mean spacings), and vertices are keyed by coordinates (a repeated point
+    keeps its first position and its last density).  Pinned by tests/golden/domain_pipeline.json."""
+    base_length = float(base_length)
+    table = {}
+    for i, p in enumerate(points):
+        table[tuple(p)] = float(densities[i])
+    lst = list(table.items())
+    res: List[Point] = []
+    for i, (k, v) in enumerate(lst):
+        prev, pv = lst[i - 1]
+        B = v * base_length
+        A = pv * base_length
+        L = math.sqrt((prev[0] - k[0]) ** 2 + (prev[1] - k[1]) ** 2)
+        x = round((2 * L - A - B) / (A + B))
+        e = (B - A) / x
+        angle = clockwise_angle(prev, k)
+        inter = [A * (j + 1) + e * (j ** 2 + j) / 2 for j in range(x)]
+        inter.append(L)
+        if i == len(lst) - 1 and (len(res) + len(inter)) % 2 == 1:
+            inter.pop(int(len(inter) / 2))
+        res.extend((prev[0] + t * math.cos(angle), prev[1] + t * math.sin(angle)) for t in inter)
+    return res
+
+
+def check_clockwise(points: Sequence[Point]) -> bool:
+    """ui/tk-ui.py:169-176: the shoelace sum  sum(x[i-1] * y[i] - y[i-1] * x[i])  is negative."""
+    return sum([points[i - 1][0] * p[1] - points[i - 1][1] * p[0] for i, p in enumerate(points)]) < 0
+
+
+def normalise_clockwise(points: Sequence[Point]) -> List[Point]:
+    """What file_save writes (ui/tk-ui.py:84-101): the point list as is when check_clockwise(), reversed otherwise."""
+    pts = list(points)
+    return pts if check_clockwise(pts) else list(reversed(pts))
+
+
+def density_domain(points: Sequence[Point], base_length: float, densities: Sequence[float] | None = None) -> List[Point]:
+    """The reference's whole route from a drawn / generated pixel polygon to a domain ring: calculate_density ->
+    save with clockwise normalisation -> read_polygon's division by 100 (general/polygon.py:110-117)."""
+    dens = [1.0] * len(points) if densities is None else densities
+    return [(p[0] / 100, p[1] / 100) for p in normalise_clockwise(calculate_density(points, base_length, dens))]
+
+
+def densify(points: Sequence[Point], target: float, even: bool = False) -> List[Point]:
+    """Uniform edge split: every edge into ceil(length / target) equal pieces.  NOT the reference's
+    calculate_density (that is the function above, which raises on edges of 0.5-1.5 spacings and therefore cannot be
+    applied to arbitrary generated polygons): this is the total, always-defined densification bench.py's synthetic
+    config-5 rings use.  even=True gives the last edge one more piece when the vertex count would be odd."""
     n = len(points)
+    pieces = []
     for i in range(n):
         x0, y0 = points[i]
         x1, y1 = points[(i + 1) % n]
-        length = math.hypot(x1 - x0, y1 - y0)
-        pieces = max(1, int(math.ceil(length / target)))
-        for j in range(pieces):
-            t = j / pieces
+        dx, dy = x1 - x0, y1 - y0
+        length = math.sqrt(dx * dx + dy * dy)
+        pieces.append(max(1, int(math.ceil(length / target))))
+    if even and sum(pieces) % 2 == 1:
+        pieces[-1] += 1
+    out: List[Point] = []
+    for i in range(n):
+        x0, y0 = points[i]
+        x1, y1 = points[(i + 1) % n]
+        for j in range(pieces[i]):
+            t = j / pieces[i]
             out.append((x0 + (x1 - x0) * t, y0 + (y1 - y0) * t))
     return out
 
 
-def random_domain(seed: int, num_verts: int | None = None, edge: float = 0.45) -> List[Point]:
-    """Config-5 style domain: a random star-shaped polygon in pixel coordinates, /100, made
-    clockwise (as ui/tk-ui.py:84-101,169-176 does on save) and densified to ``edge``."""
+def random_polygon_px(seed: int, num_verts: int | None = None) -> List[Tuple[int, int]]:
+    """The raw polygon of a config-5 domain: generate_polygon (pixel coordinates, CCW) from random.Random(seed) with
+    num_verts = randint(8, 64) unless given, consecutive duplicates (int() truncation) dropped; regenerated from the
+    same stream until at least 5 distinct vertices remain."""
     rng = random.Random(seed)
     nv = num_verts if num_verts is not None else rng.randint(8, 64)
     while True:
         raw = generate_polygon(num_verts=nv, rng=rng)
-        pts = []
-        for p in raw:                      # drop consecutive duplicates from int() truncation
-            q = (p[0] / 100, p[1] / 100)
-            if not pts or q != pts[-1]:
-                pts.append(q)
+        pts: List[Tuple[int, int]] = []
+        for p in raw:
+            if not pts or p != pts[-1]:
+                pts.append(p)
         if len(pts) > 1 and pts[0] == pts[-1]:
             pts.pop()
         if len(pts) >= 5:
-            break
-    if signed_area2(pts) > 0:
-        pts.reverse()
-    pts = densify(pts, edge)
-    # coordinates on the 1e-4 grid, like every vertex the environment itself creates
+            return pts
+
+
+def random_domain(seed: int, num_verts: int | None = None, edge: float = 0.45) -> List[Point]:
+    """Config-5 style synthetic domain: random_polygon_px / 100, made clockwise with the reference's orientation rule
+    (normalise_clockwise), uniformly densified to ``edge`` with an even vertex count, coordinates on the 1e-4 grid
+    (like every vertex the environment itself creates).  The generator is the reference's (pinned by fixture); the
+    densification is the uniform split above, not calculate_density -- see densify()."""
+    pts = [(p[0] / 100, p[1] / 100) for p in random_polygon_px(seed, num_verts)]
+    pts = densify(normalise_clockwise(pts), edge, even=True)
     return [(round(x, 4), round(y, 4)) for x, y in pts]
 
 

@@ -63,3 +63,61 @@ def test_golden_covers_edge_cases():
     assert any(t["obs_none"].any() for t in trs), "no None observation"
     assert any((t["ring_len"] == 4).any() for t in trs) and any((t["ring_len"] == 5).any() for t in trs)
     assert any((~np.isnan(t["new_xy"][:, 0])).any() for t in trs)
+
+
+# ------------------------------------------------------------------------------------------------ move() API (8f row 4)
+from conftest import move_golden_names  # noqa: E402
+
+
+def replay_move(tr, make_env, do_reset, do_move, state_of):
+    """Shared by the oracle test (here) and the GPU test: replays a recorded move() trace through `do_move` and compares
+    with what the reference returned.  codes: 0 ok, 1 obs None, 2 the reference raises, 3 it would smooth."""
+    env = make_env(tr)
+    obs = do_reset(env)
+    np.testing.assert_array_equal(obs, tr["reset_obs"])
+    seen = np.zeros(4, int)
+    for t in range(len(tr["points"])):
+        obs, done, comp, code = do_move(env, tr["points"][t], float(tr["types"][t]))
+        assert code == tr["code"][t], (t, code, tr["code"][t])
+        seen[code] += 1
+        if code == 0:
+            np.testing.assert_array_equal(obs, tr["obs"][t], err_msg=f"obs move {t}")
+        if code != 2:
+            assert done == bool(tr["done"][t]) and comp == bool(tr["complete"][t]), t
+        st = state_of(env)
+        n = int(tr["ring_len"][t])
+        assert st["n"] == n, t
+        np.testing.assert_array_equal(st["ring_ids"], tr["ring_ids"][t, :n], err_msg=f"ring move {t}")
+        assert st["n_elem"] == tr["n_elem"][t] and st["n_not_valid"] == tr["n_not_valid"][t], t
+        if code == 0:
+            assert st["ref_id"] == tr["ref_id"][t], t
+        if not np.isnan(tr["new_xy"][t, 0]):
+            np.testing.assert_array_equal(st["last_vertex"], tr["new_xy"][t])
+        if tr["was_reset"][t]:
+            do_reset(env)
+    return seen
+
+
+@pytest.mark.parametrize("name", move_golden_names())
+def test_oracle_move_matches_reference_trace(name):
+    tr = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+
+    def state_of(env):
+        ids, _ = env.ring()
+        sc = env.scalars()
+        _, vxy = env.elements()
+        return dict(n=len(ids), ring_ids=ids, n_elem=sc["n_elem"], n_not_valid=env.not_valid_count(),
+                    ref_id=env.ref_id(), last_vertex=vxy[sc["n_vert"] - 1])
+
+    replay_move(tr, lambda tr: RefEnv(tr["domain_xy"], tr["consts"][0], tr["consts"][2], tr["consts"][3]),
+                lambda env: env.reset(static=True)[0], lambda env, p, ty: env.move(p, ty), state_of)
+
+
+def test_move_golden_covers_every_return_path():
+    trs = [dict(np.load(os.path.join(GOLDEN_DIR, n + ".npz"))) for n in move_golden_names()]
+    codes = np.sum([np.bincount(t["code"], minlength=4) for t in trs], axis=0)
+    assert (codes > 0).all(), codes                 # ok / None observation / raises / needs smoothing
+    assert any(((t["done"] == 1) & (t["complete"] == 1)).any() for t in trs)      # ring of 4: complete
+    assert any(((t["done"] == 1) & (t["complete"] == 0) & (t["code"] == 0)).any() for t in trs)  # ring of 5
+    assert any((t["n_not_valid"] > 8).any() for t in trs)
+    assert any((~np.isnan(t["new_xy"][:, 0])).any() for t in trs)
