@@ -121,6 +121,14 @@ int meshenv_group_size(const MeshEnv *h);
 int meshenv_reset(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev);
 
 /*
+ * reset(static=True): rl/boundary_env.py:67 -> find_next_state(static=static) -> PointEnvironment(static=True)
+ * (general/components.py:1213-1218): observation entry 1 (row 0, second value) carries 0 instead of the area ratio.
+ * is_static = 0 is meshenv_reset.  Also empties the move() API's not_valid_points of the reset envs
+ * (rl/boundary_env.py:73).
+ */
+int meshenv_reset_static(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev, int is_static);
+
+/*
  * step(): rl/boundary_env.py:113-263 for all envs, one kernel launch.
  *   actions_dev[n_envs*3] float32   (rule type, x, y) as SB3 hands them over
  *   obs_dev[n_envs*18]    float32   next observation (after auto-reset: the first observation of
@@ -144,6 +152,38 @@ int meshenv_step(MeshEnv *h, const float *actions_dev, float *obs_dev, double *r
  */
 int meshenv_rollout(MeshEnv *h, int n_steps, const float *actions_dev, float *obs_dev, double *reward_dev,
                     uint8_t *done_dev, uint8_t *complete_dev, int auto_reset);
+
+/*
+ * move(new_point, type): rl/boundary_env.py:265-432, the deterministic extraction API the reference's ANN / testbed
+ * scripts drive, for all envs in one launch and for Python-float arguments:
+ *   points_dev[n_envs*2]  float64  (radius fraction, angle): the candidate point is
+ *                                  base_length * radius * r * (cos a, sin a) in the reference vertex's frame, rounded
+ *                                  to 6 places, scale 1 (rl/boundary_env.py:266-269, 105)
+ *   type_dev[n_envs]      float64  rule selector: <= 0.3 the rule -1 quad, >= 0.7 the rule +1 quad, else the new point
+ *                                  (TYPE_THRESHOLD, rl/boundary_env.py:19, 286-310; no find_same_point here)
+ *   obs_dev[n_envs*18]    float32  next observation, static form (see meshenv_reset_static)
+ *   done_dev / complete_dev        done: ring <= 5 after a valid move; complete: ring <= 4
+ *   code_dev[n_envs]      uint8    MESHENV_MOVE_*
+ * The reward is always 0 in the reference and is not returned.  A rejected move appends the reference vertex to the
+ * env's not_valid_points, which the next selection skips (general/mesh.py:284-288); a valid move empties the list.
+ * current_area and failed_num are not touched (the reference's move() does not).  No auto-reset: reset the envs with
+ * done != 0 or code >= MESHENV_MOVE_RAISES through meshenv_reset_static with a mask.
+ */
+enum {
+    MESHENV_MOVE_OK = 0,
+    MESHENV_MOVE_NONE = 1,            /* the observation is None (zeros): no reference vertex on a ring of <= 4 */
+    MESHENV_MOVE_RAISES = 2,          /* ring <= 5 (or no reference vertex) on entry: the reference raises
+                                         UnboundLocalError (`is_complete` unbound, rl/boundary_env.py:283-285, 432);
+                                         nothing is changed, the cached observation is returned */
+    MESHENV_MOVE_NEEDS_SMOOTHING = 3  /* no selectable reference vertex on a ring of more than 4: the reference runs
+                                         smooth_pave (general/mesh.py:1100-1392, not built here) and retries; this
+                                         library ends the episode instead: done = 1, complete = 0 */
+};
+int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, float *obs_dev, uint8_t *done_dev,
+                 uint8_t *complete_dev, uint8_t *code_dev);
+
+/* Host-side readout of one env's not_valid_points (synchronises the stream): xy_host[2*cap_points], *count = length. */
+int meshenv_get_not_valid(MeshEnv *h, int env, double *xy_host, int cap_points, int32_t *count);
 
 /*
  * Multi-GPU exchange message.  With msg_dev != NULL every following meshenv_step / meshenv_rollout also writes

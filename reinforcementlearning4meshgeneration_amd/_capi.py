@@ -12,6 +12,7 @@ ACT_DIM = 3
 
 ST_NO_REFERENCE = 1
 ST_LOG_OVERFLOW = 2
+MOVE_OK, MOVE_NONE, MOVE_RAISES, MOVE_NEEDS_SMOOTHING = 0, 1, 2, 3
 
 
 class MeshEnvParams(C.Structure):
@@ -38,6 +39,7 @@ EXPORTS = [
     "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times", "meshenv_selftest", "meshenv_set_packed_output",
     "meshenv_actor_create", "meshenv_actor_destroy", "meshenv_actor_set_stream", "meshenv_actor_load",
     "meshenv_actor_forward", "meshenv_actor_sample", "meshenv_get_last_episode", "meshenv_element_quality",
+    "meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid",
 ]
 
 
@@ -77,6 +79,9 @@ def load():
     L.meshenv_group_size.argtypes = [vp]
     L.meshenv_group_size.restype = C.c_int
     L.meshenv_reset.argtypes = [vp, u8p, f32p]
+    L.meshenv_reset_static.argtypes = [vp, u8p, f32p, C.c_int]
+    L.meshenv_move.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.meshenv_get_not_valid.argtypes = [vp, C.c_int, vp, C.c_int, i32p]
     L.meshenv_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.meshenv_rollout.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
     L.meshenv_get_status.argtypes = [vp, vp]
@@ -101,7 +106,7 @@ def load():
     for name in ("meshenv_actor_create", "meshenv_actor_set_stream", "meshenv_actor_load", "meshenv_actor_forward",
                  "meshenv_actor_sample"):
         getattr(L, name).restype = C.c_int
-    for name in ("meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_reset", "meshenv_step",
+    for name in ("meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid", "meshenv_set_stream", "meshenv_num_envs", "meshenv_max_ring", "meshenv_reset", "meshenv_step",
                  "meshenv_rollout", "meshenv_get_status", "meshenv_get_state", "meshenv_get_elements",
                  "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times", "meshenv_get_last_episode",
                  "meshenv_element_quality"):

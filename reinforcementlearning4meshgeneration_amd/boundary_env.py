@@ -53,11 +53,9 @@ class BoudaryEnv:  # the reference's spelling
 
     # ------------------------------------------------------------------ Gym surface
     def reset(self, *, seed=None, static=False, options=None):
-        if static:
-            raise NotImplementedError("static=True (observation with area_ratio forced to 0) is not part of the hot path")
         if seed is not None and hasattr(self.action_space, "seed"):
             self.action_space.seed(seed)
-        obs = self._vec.reset().cpu().numpy()[0].copy()
+        obs = self._vec.reset(static=bool(static)).cpu().numpy()[0].copy()
         self.current_state = obs
         return (obs, {}) if self.api == "gymnasium" else obs
 
@@ -74,6 +72,31 @@ class BoudaryEnv:  # the reference's spelling
         if self.api == "gymnasium":
             return obs_np, reward, done_b and comp_b, done_b and not comp_b, info
         return obs_np, reward, done_b, info
+
+    def move(self, new_point, type, lr_1=None, lr_2=None):
+        """rl/boundary_env.py:265-432: deterministic extraction driven by (radius fraction, angle) and a rule selector;
+        returns (obs | None, 0, done, {'is_complete': bool}) like the reference.  Two of its paths differ by necessity:
+        on a finished ring (<= 5 vertices) the reference leaves `is_complete` unbound and raises UnboundLocalError --
+        so does this; where the reference would run smooth_pave (no selectable reference vertex on a ring of more than
+        4; the smoothing is not built) the episode ends here with done = True, is_complete = False."""
+        import torch
+
+        from . import _capi
+        pts = torch.tensor([[float(new_point[0]), float(new_point[1])]], dtype=torch.float64, device=self._vec.device)
+        typ = torch.tensor([float(type)], dtype=torch.float64, device=self._vec.device)
+        obs, done, comp, code = self._vec.move(pts, typ)
+        code = int(code.cpu()[0])
+        if code == _capi.MOVE_RAISES:
+            raise UnboundLocalError("local variable 'is_complete' referenced before assignment "
+                                    "(move() on a ring of <= 5 vertices, as in the reference)")
+        obs_np = obs.cpu().numpy()[0].copy() if code == _capi.MOVE_OK else None
+        self.current_state = obs_np
+        return obs_np, 0, bool(done.cpu()[0]), {"is_complete": bool(comp.cpu()[0])}
+
+    @property
+    def not_valid_points(self):
+        """[k, 2] coordinates of the reference vertices rejected since the last valid move (rl/boundary_env.py:47)."""
+        return self._vec.get_not_valid(0)
 
     def seed(self, seed=None):
         if hasattr(self.action_space, "seed"):

@@ -62,6 +62,22 @@ __device__ __forceinline__ double round4_py(double x)
     return (y < 4503599627370496.0) ? q : x;  // huge / inf / NaN pass through
 }
 
+// Python's round(float, 6) (the move() API rounds its local coordinates to 6 places, B:269): the same construction with
+// scale 1e6 and the IEEE divide (not a hot path).
+__device__ __forceinline__ double round6_py(double x)
+{
+    const double ax = fabs(x);
+    const double y = ax * 1e6;
+    const double e = fma(ax, 1e6, -y);
+    const double f = floor(y);
+    const double t = (y - f) - 0.5;
+    const double s = t + e;
+    const bool up = (s > 0.0) || (s == 0.0 && ((((long long)f) & 1LL) != 0));
+    const double r = up ? f + 1.0 : f;
+    const double q = copysign(r / 1e6, x);
+    return (y < 4503599627370496.0) ? q : x;
+}
+
 // round(np.float64, 4): numpy's multiply / rint / divide
 __device__ __forceinline__ double round4_np(double x)
 {

@@ -42,6 +42,9 @@ struct MeshEnv {
     int timing = 0;              // 0 = off, k = bracket every other group of k consecutive launches
     long long launch_count = 0;
     std::vector<hipEvent_t> ev;  // 2 * MESHENV_TIMING_POOL events, created on first use
+    // move() API state, allocated by the first meshenv_move: not_valid_points per env
+    double2 *nv_xy = nullptr;    // [E][cap]
+    int32_t *nv_count = nullptr; // [E]
     long long ev_count = 0;      // launches recorded since timing was armed
 };
 
@@ -335,7 +338,8 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
 
     hipLaunchKernelGGL(k_init_domains, dim3(n_domains), dim3(64), lds, h->stream, S, cap);
     CREATE_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_reset, dim3(n_envs), dim3(64), lds, h->stream, S, cap, (const uint8_t *)nullptr, (float *)nullptr, 1, 0ULL);
+    hipLaunchKernelGGL(k_reset, dim3(n_envs), dim3(64), lds, h->stream, S, cap, (const uint8_t *)nullptr, (float *)nullptr, 1, 0ULL,
+                       0, (int32_t *)nullptr);
     CREATE_HIP(hipGetLastError());
     CREATE_HIP(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
@@ -364,13 +368,65 @@ int meshenv_num_envs(const MeshEnv *h) { return h ? h->n_envs : MESHENV_E_ARG; }
 int meshenv_max_ring(const MeshEnv *h) { return h ? h->max_ring : MESHENV_E_ARG; }
 int meshenv_group_size(const MeshEnv *h) { return h ? h->group : MESHENV_E_ARG; }
 
-int meshenv_reset(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev)
+int meshenv_reset_static(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev, int is_static)
 {
     if (!h) return MESHENV_E_ARG;
     MESHENV_ON_DEVICE(h);
     hipLaunchKernelGGL(k_reset, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, mask_dev, obs_dev, 0,
-                       (unsigned long long)h->steps_done);
+                       (unsigned long long)h->steps_done, is_static ? 1 : 0, h->nv_count);
     HIP_TRY(h, hipGetLastError());
+    return MESHENV_OK;
+}
+
+int meshenv_reset(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev) { return meshenv_reset_static(h, mask_dev, obs_dev, 0); }
+
+static int ensure_move_state(MeshEnv *h)
+{
+    if (h->nv_xy) return MESHENV_OK;
+    const size_t total = (size_t)h->n_envs * (size_t)h->cap;
+    int rc = dev_alloc(h, &h->nv_xy, total);
+    if (rc != MESHENV_OK) return rc;
+    rc = dev_alloc(h, &h->nv_count, (size_t)h->n_envs);
+    if (rc != MESHENV_OK) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->nv_count, 0, sizeof(int32_t) * (size_t)h->n_envs, h->stream));
+    if (move_lds_bytes(h->cap) > 64 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_move, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return MESHENV_OK;
+}
+
+int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, float *obs_dev, uint8_t *done_dev,
+                 uint8_t *complete_dev, uint8_t *code_dev)
+{
+    if (!h) return MESHENV_E_ARG;
+    if (!points_dev || !type_dev || !obs_dev || !done_dev || !complete_dev || !code_dev) return fail_arg(h, "meshenv_move: null device pointer");
+    if (move_lds_bytes(h->cap) > 160 * 1024) return fail_arg(h, "meshenv_move: ring too long for the move kernel's LDS (60 B per vertex)");
+    MESHENV_ON_DEVICE(h);
+    const int rc = ensure_move_state(h);
+    if (rc != MESHENV_OK) return rc;
+    hipLaunchKernelGGL(k_move, dim3(h->n_envs), dim3(64), move_lds_bytes(h->cap), h->stream, h->S, h->cap, points_dev, type_dev,
+                       obs_dev, done_dev, complete_dev, code_dev, h->nv_xy, h->nv_count);
+    HIP_TRY(h, hipGetLastError());
+    return MESHENV_OK;
+}
+
+int meshenv_get_not_valid(MeshEnv *h, int env, double *xy_host, int cap_points, int32_t *count)
+{
+    if (!h || !count) return MESHENV_E_ARG;
+    if (env < 0 || env >= h->n_envs) {
+        h->err = "meshenv_get_not_valid: env out of range";
+        return MESHENV_E_RANGE;
+    }
+    *count = 0;
+    if (!h->nv_xy) return MESHENV_OK;  // move() never called: the list is empty
+    MESHENV_ON_DEVICE(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int32_t n = 0;
+    HIP_TRY(h, hipMemcpy(&n, h->nv_count + env, sizeof(n), hipMemcpyDeviceToHost));
+    *count = n;
+    if (xy_host && n > 0) {
+        const int m = n < cap_points ? n : cap_points;
+        HIP_TRY(h, hipMemcpy(xy_host, h->nv_xy + (size_t)env * h->cap, sizeof(double2) * (size_t)m, hipMemcpyDeviceToHost));
+    }
     return MESHENV_OK;
 }
 

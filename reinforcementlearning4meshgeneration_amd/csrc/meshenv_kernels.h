@@ -225,6 +225,29 @@ __device__ __forceinline__ int select_reference(const Ctx &c)
     return lane_i32(bi, (int)__ffsll((long long)hit) - 1);
 }
 
+// find_reference_point with not_valid_points (M:284-288, the move() API): the first list entry that is not within
+// 0.001 of a listed point (is_vertex_inside_list, M:428-433).  nv = the env's list (LDS), n_nv its length.
+__device__ __forceinline__ int select_reference_nv(const Ctx &c, const double2 *nv, int n_nv)
+{
+    double bk = kInf;
+    int bs = kNotCand, bi = -1;
+    for (int i = c.lane; i < c.n; i += 64) {
+        const int st = c.stamp[i];
+        if (st != kNotCand) {
+            const P2 v = ldp(c, i);
+            bool listed = false;
+            for (int k = 0; k < n_nv; k++) listed = listed || dist(mkp(nv[k].x, nv[k].y), v) < 0.001;
+            const double k = c.key[i];
+            if (!listed && (k < bk || (k == bk && st > bs))) { bk = k; bs = st; bi = i; }
+        }
+    }
+    const double kmin = wave_min_f64(bk);
+    if (!(kmin < kInf)) return -1;
+    const int smax = wave_max_i32(bk == kmin ? bs : kNotCand);
+    const unsigned long long hit = __ballot(bk == kmin && bs == smax);
+    return lane_i32(bi, (int)__ffsll((long long)hit) - 1);
+}
+
 // the two angles of MeshGeneration.check_boundary_point (M:202-231) for ring slot `index`:
 // which = 0 -> cw(v; ring[index+1], ring[index-1]); which = 1 -> cw(v; ring[index+2], ring[index-2])
 __device__ __forceinline__ void key_angle_terms(const Ctx &c, int index, int which, double &cc, double &dd)
@@ -262,12 +285,15 @@ struct BqArgs {
 
 // find_next_state, B:504-571 -> PointEnvironment.get_neighbors C:1073-1082 + get_radius_points C:1184-1282.
 // Updates c.ref, c.bl, c.ct/st (action frame of the new state), c.obs (lanes 0..17), c.status; fills bq outputs.
-__device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArgs &bq)
+// (is_static / nv: compile-time constants at every call; the move() API passes PointEnvironment(static=True) and its
+// not_valid_points list, C:1213-1218, M:284-288)
+__device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArgs &bq, const bool is_static = false,
+                                                const double2 *nv = nullptr, int n_nv = 0)
 {
     const Params &p = S.prm;
     const int lane = c.lane, n = c.n;
     wave_sync();
-    const int idx = select_reference(c);
+    const int idx = nv ? select_reference_nv(c, nv, n_nv) : select_reference(c);
     c.ref = idx;
     MESHENV_STAMP(c, 9);
     const bool none = idx < 0;  // the reference returns None here; the reward terms are still needed
@@ -472,7 +498,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     if (lane < 6) {
         const int row = lane < 3 ? lane : 8 - (lane - 3);
         float v1;
-        if (lane == 0) v1 = (float)area_ratio;
+        if (lane == 0) v1 = is_static ? 0.0f : (float)area_ratio;
         else if (lane == 3) v1 = (float)theta;
         else if (lane < 3) v1 = (float)(na < kPi ? na : fmax(na, 1.5 * kPi) - 2 * kPi);
         else v1 = (float)fmin(na, clipmax);
@@ -821,7 +847,11 @@ struct Decision {
 // boundary intersection.  a0 = rule type, (a1, a2) = candidate point in the local frame.  On success the quad,
 // its corner angles / edge lengths and the speculative candidate-key and boundary-quality angles are in c.sc.
 // (pre_reject: evaluate the quad's corner test before the point-in-polygon pass; a compile-time constant at each call)
-__device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a0, float a1, float a2, const bool pre_reject)
+// (is_move: the move() API, B:265-326 -- the point comes as (radius fraction, angle) Python floats in mv_r / mv_a, the
+// rule from mv_type against TYPE_THRESHOLD = 0.3, and there is no find_same_point; a compile-time constant per call)
+__device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a0, float a1, float a2, const bool pre_reject,
+                                              const bool is_move = false, double mv_r = 0.0, double mv_a = 0.0,
+                                              double mv_type = 0.5)
 {
     const Params &prm = S.prm;
     const int lane = c.lane;
@@ -852,18 +882,26 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
     int near_count = 0;
     P2 new_point = mkp(0.0, 0.0);
     int rule;
-    if (a0 <= -0.5f) rule = -1;
-    else if (a0 >= 0.5f) rule = 1;
+    const bool rule_m1 = is_move ? (mv_type <= 0.3) : (a0 <= -0.5f);
+    const bool rule_p1 = is_move ? (mv_type >= 1 - 0.3) : (a0 >= 0.5f);
+    if (rule_m1) rule = -1;
+    else if (rule_p1) rule = 1;
     else {
         rule = 0;
         // action_2_point -> detransformation, B:616-625, B:98-106, D:67-83; cos/sin of the frame angle are
         // per-state values computed with the observation
-        const double px = (double)round4_npf(a1), py = (double)round4_npf(a2);
+        double px = (double)round4_npf(a1), py = (double)round4_npf(a2);
+        if (is_move) {  // B:266-269: (bl * radius * r) * cos / sin(angle), rounded to 6 places, scale 1 (B:105)
+            const SinCos sc = sincos_nc(mv_a);
+            const double br = (c.bl * prm.radius) * mv_r;
+            px = round6_py(br * sc.c);
+            py = round6_py(br * sc.s);
+        }
         const P2 p0 = ldp(c, index);
         double ox = c.ct * px + c.st * py;
         double oy = -c.st * px + c.ct * py;
-        ox *= c.bl;
-        oy *= c.bl;
+        ox *= is_move ? 1.0 : c.bl;
+        oy *= is_move ? 1.0 : c.bl;
         ox += p0.x;
         oy += p0.y;
         new_point = mkp(uniform_f64(round4_np(ox)), uniform_f64(round4_np(oy)));
@@ -923,11 +961,12 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
         f.mp0 = -1; f.mp1 = wrapi(index - 1, n); f.mp2 = index; f.mp3 = wrapi(index + 1, n);
         f.max_dist = quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3));
         bool same;
-        near_count = near_filter_pass(c, f, new_point, prm.same_eps, same);
+        near_count = near_filter_pass(c, f, new_point, is_move ? 0.0 : prm.same_eps, same);
         if (same) rule = -1;  // existing point: the rule -1 quad, B:168-175 (its own filter pass follows)
         else { new_vertex = true; have_filter = true; }
     }
-    if (!new_vertex && (c.status & (rule == -1 ? kStRm1Bad : kStRp1Bad))) {
+    // (move(): a rejection changes the reference vertex without changing the ring, so the memo does not apply there)
+    if (!is_move && !new_vertex && (c.status & (rule == -1 ? kStRm1Bad : kStRp1Bad))) {
         d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;  // B:248, outcome remembered from an earlier attempt on this state
         return d;
     }
@@ -984,7 +1023,7 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
     MESHENV_STAMP(c, 5);
     if (!ok) {
         d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;  // B:248
-        if (!new_vertex) c.status |= (rule == -1 ? kStRm1Bad : kStRp1Bad);
+        if (!new_vertex && !is_move) c.status |= (rule == -1 ? kStRm1Bad : kStRp1Bad);
         return d;
     }
     d.ok = 1;
@@ -1001,7 +1040,10 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
 // next observation.  Runs on whichever wavefront holds the env's LDS region (c) and the decision.
 // (upd_done != nullptr: CU-group kernel with a helper wavefront -- the reward is computed there from the post-update
 // ring; this wave publishes the updated ring through *upd_done and skips every reward-only computation)
-__device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d, volatile int *upd_done = nullptr)
+// (is_move: move() extracts the element without reward, current_area or failed_num bookkeeping and observes with
+// static=True and its not_valid_points, B:328-345)
+__device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d, volatile int *upd_done = nullptr,
+                                          const bool is_move = false, const double2 *nv = nullptr, int n_nv = 0)
 {
     const bool has_helper = upd_done != nullptr;
     const Params &prm = S.prm;
@@ -1106,9 +1148,15 @@ __device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d
     const bool finished = c.n <= 5;  // B:232-238
     if (finished && c.n == 4) log_quad(c, S, c.id[0], c.id[1], c.id[2], c.id[3]);
     // current_area -= mesh_area (B:200) happens inside: the area needs sin(corner angles), a stage-B job
-    find_next_state(c, S, bq);
+    if (is_move) {
+        bq.mode = 0;
+        bq.skip = false;
+        find_next_state(c, S, bq, true, nv, n_nv);
+    } else {
+        find_next_state(c, S, bq);
+    }
     MESHENV_STAMP(c, 14);
-    if (!has_helper) {
+    if (!has_helper && !is_move) {
         const double mesh_area = bq.mesh_area;
         // get_quality(mesh, 2), M:1733-1740
         const double quality = e_reward + 1 * (bq.b_reward - 1);
@@ -1322,7 +1370,7 @@ __global__ void __launch_bounds__(64) k_init_domains(DevState S, int cap)
 }
 
 __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t *mask, float *obs_out, int first,
-                                               unsigned long long step_now)
+                                               unsigned long long step_now, int is_static, int32_t *nv_count)
 {
     extern __shared__ double2 smem[];
     Ctx c;
@@ -1347,6 +1395,8 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
     }
     const int n_old = c.n;
     reset_from_domain(c, S);
+    if (is_static && c.lane == 1) c.obs = 0.0f;   // reset(static=True): row 0 carries 0 instead of the area ratio (C:1213-1218)
+    if (nv_count && c.lane == 0) nv_count[env] = 0;  // self.not_valid_points = [], B:73
     if (c.lane == 0) {
         EnvCounters z;
         if (first) {
@@ -1460,6 +1510,78 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
 #else
     if (k_dirty && c.lane == 0) S.cnt[env] = k;
 #endif
+}
+
+// ------------------------------------------------------------------------------------------ move() API
+
+enum { kMoveOk = 0, kMoveNone = 1, kMoveRaises = 2, kMoveNeedsSmoothing = 3 };
+
+__host__ __device__ __forceinline__ size_t move_lds_bytes(int cap) { return lds_bytes_for(cap) + sizeof(double2) * (size_t)cap; }
+
+// BoudaryEnv.move(new_point, type), B:265-432, for every env: one wavefront per env like k_step.  points[e] = (radius
+// fraction, angle), types[e] the rule selector.  No reward (the reference returns 0), no current_area / failed_num
+// bookkeeping; the reference vertex of a rejected move joins the env's not_valid_points (nv_xy / nv_count, staged in LDS)
+// and is skipped by the selection; the observation is the static one.  code[e]: kMoveOk, kMoveNone (observation None),
+// kMoveRaises (ring <= 5 or no reference vertex on entry: the reference raises UnboundLocalError; nothing changes),
+// kMoveNeedsSmoothing (no selectable vertex left on a ring of more than 4: the reference runs smooth_pave -- not built
+// -- and retries; here done = 1, complete = 0 and the caller resets).
+__global__ void __launch_bounds__(64) k_move(DevState S, int cap, const double *__restrict__ points,
+                                              const double *__restrict__ types, float *__restrict__ obs_out,
+                                              uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
+                                              uint8_t *__restrict__ code, double2 *__restrict__ nv_xy,
+                                              int32_t *__restrict__ nv_count)
+{
+    extern __shared__ double2 smem[];
+    Ctx c;
+    carve_lds(c, smem, cap);
+    double2 *nv = (double2 *)((char *)smem + lds_bytes_for(cap));
+    const int env = blockIdx.x;
+    const double mv_r = points[2 * (size_t)env], mv_a = points[2 * (size_t)env + 1], mv_type = types[env];
+    int n_nv = uniform_i32(nv_count[env]);
+    load_env(c, S, env);
+    const int lane = c.lane;
+    if (c.ref < 0 || c.n <= 5) {
+        if (lane < kObsDim) obs_out[(size_t)env * kObsDim + lane] = c.obs;
+        if (lane == 0) { done[env] = 0; complete[env] = 0; code[env] = (uint8_t)kMoveRaises; }
+        return;
+    }
+    c.status &= ~(kStRm1Bad | kStRp1Bad);  // the memo of step() is tied to the reference vertex, which a move may change
+    double2 *gnv = nv_xy + (size_t)env * cap;
+    for (int k = lane; k < n_nv; k += 64) nv[k] = gnv[k];
+    wave_sync();
+    const double2 refpt = c.xy[c.ref];  // the reference vertex of this move, before any update
+    Decision d = env_check(c, S, 0.0f, 0.0f, 0.0f, false, true, mv_r, mv_a, mv_type);
+    if (d.ok) {
+        env_apply(c, S, d, nullptr, true, nv, n_nv);  // B:345: the selection still sees the old not_valid_points
+        n_nv = 0;                                     // B:365
+    } else {
+        // B:359-361: `reference_point not in not_valid_points` is object identity -- a ring vertex is listed once
+        bool listed = false;
+        for (int k = lane; k < n_nv; k += 64) listed = listed || (nv[k].x == refpt.x && nv[k].y == refpt.y);
+        if (__ballot(listed) == 0ULL) {
+            if (lane == 0) {
+                nv[n_nv] = refpt;
+                gnv[n_nv] = refpt;
+            }
+            n_nv += 1;
+        }
+        wave_sync();
+        BqArgs bq;
+        bq.skip = false;
+        bq.mode = 0; bq.a = 0; bq.b = 0; bq.ang0 = 0; bq.ang1 = 0; bq.q_ang0 = 0; bq.q_ang2 = 0; bq.half01 = 0; bq.half23 = 0;
+        find_next_state(c, S, bq, true, nv, n_nv);
+        c.ring_dirty = true;  // reference vertex, base length, action frame and observation moved: full record write-back
+    }
+    const bool none = c.ref < 0;
+    const int cd = none ? (c.n > 4 ? kMoveNeedsSmoothing : kMoveNone) : kMoveOk;
+    if (lane < kObsDim) obs_out[(size_t)env * kObsDim + lane] = c.obs;
+    if (lane == 0) {
+        done[env] = (uint8_t)((d.done || cd == kMoveNeedsSmoothing) ? 1 : 0);
+        complete[env] = (uint8_t)(c.n <= 4 ? 1 : 0);   // B:403-432
+        code[env] = (uint8_t)cd;
+        nv_count[env] = n_nv;
+    }
+    store_env(c, S);
 }
 
 // ------------------------------------------------------------------------------------------ CU-group step kernel

@@ -169,15 +169,45 @@ class MeshVecEnv:
             pass
 
     # ------------------------------------------------------------------ tensor-native API
-    def reset(self, mask=None):
-        """reset() of rl/boundary_env.py:67-84 for all envs (or those with mask != 0).  Returns obs [n,18]."""
+    def reset(self, mask=None, static=False):
+        """reset(static) of rl/boundary_env.py:67-84 for all envs (or those with mask != 0).  Returns obs [n,18].
+        static=True is PointEnvironment(static=True): observation entry 1 carries 0 instead of the area ratio."""
         self._bind_stream()
         mptr = None
         if mask is not None:
             mask = mask.to(device=self.device, dtype=self._torch.uint8).contiguous()
             mptr = C.c_void_p(mask.data_ptr())
-        self._check(self._L.meshenv_reset(self._handle, mptr, C.c_void_p(self.obs.data_ptr())), "meshenv_reset")
+        self._check(self._L.meshenv_reset_static(self._handle, mptr, C.c_void_p(self.obs.data_ptr()), 1 if static else 0),
+                    "meshenv_reset_static")
         return self.obs
+
+    def move(self, points, types):
+        """move(new_point, type) of rl/boundary_env.py:265-432 for every env, one launch.
+        points: float64 CUDA [n, 2] = (radius fraction, angle); types: float64 CUDA [n] rule selectors.
+        Returns (obs [n,18] static form, done [n] uint8, complete [n] uint8, code [n] uint8 = _capi.MOVE_*); the reward is
+        always 0 in the reference and is not returned.  No auto-reset: reset(mask=done | (code >= 2), static=True)."""
+        t = self._torch
+        points = points.to(device=self.device, dtype=t.float64).contiguous()
+        types = types.to(device=self.device, dtype=t.float64).contiguous()
+        if tuple(points.shape) != (self.num_envs, 2) or tuple(types.shape) != (self.num_envs,):
+            raise ValueError(f"points must be [{self.num_envs}, 2] and types [{self.num_envs}]")
+        if not hasattr(self, "move_code"):
+            self.move_code = t.zeros(self.num_envs, dtype=t.uint8, device=self.device)
+        self._bind_stream()
+        rc = self._L.meshenv_move(self._handle, points.data_ptr(), types.data_ptr(), self.obs.data_ptr(),
+                                  self.done.data_ptr(), self.complete.data_ptr(), self.move_code.data_ptr())
+        self._check(rc, "meshenv_move")
+        return self.obs, self.done, self.complete, self.move_code
+
+    def get_not_valid(self, env: int) -> np.ndarray:
+        """not_valid_points of one env (rl/boundary_env.py:47): [k, 2] coordinates of the reference vertices whose
+        moves were rejected since the last valid move / reset."""
+        cap = self.max_ring
+        xy = np.zeros(2 * cap, np.float64)
+        n = C.c_int32(0)
+        self._check(self._L.meshenv_get_not_valid(self._handle, int(env), xy.ctypes.data, cap, C.byref(n)),
+                    "meshenv_get_not_valid")
+        return xy[:2 * n.value].reshape(-1, 2).copy()
 
     def step(self, actions):
         """One step() of every env.  actions: float32 CUDA tensor [n, 3].

@@ -1,0 +1,124 @@
+"""GPU: the move() API and reset(static=True) (first slice) through the C-ABI:
+  (a) replay of the traces recorded from the reference's own move() (tests/golden/move_*.npz) -- observations
+      bit-exact unless a device transcendental differs by an ulp (tolerance 1e-5 as everywhere, mismatches counted),
+      topology / not_valid_points / flags / return codes exact;
+  (b) 2048 envs on mixed domains in lockstep with the CPU oracle's move();
+  (c) the reference-shaped single env: return tuple, the UnboundLocalError of a finished ring, static reset."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, move_golden_names
+from test_oracle_golden import replay_move
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", move_golden_names())
+def test_hip_move_matches_reference_trace(name):
+    import torch
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv
+    tr = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    worst = [0.0]
+
+    def make(tr):
+        return MeshVecEnv([[tuple(p) for p in tr["domain_xy"]]], n_envs=1, auto_reset=False, log_capacity=1024)
+
+    def do_move(env, p, ty):
+        obs, done, comp, code = env.move(torch.tensor(p[None, :], dtype=torch.float64), torch.tensor([ty], dtype=torch.float64))
+        return obs.cpu().numpy()[0], bool(done.cpu()[0]), bool(comp.cpu()[0]), int(code.cpu()[0])
+
+    def state_of(env):
+        st = env.get_state(0)
+        _, vxy = env.get_elements(0)
+        st["n_not_valid"] = len(env.get_not_valid(0))
+        st["last_vertex"] = vxy[st["n_vert"] - 1]
+        return st
+
+    def obs_cmp(a, b, err_msg=""):   # 1e-5 as everywhere on the device side (an ulp of a device transcendental)
+        d = float(np.abs(np.asarray(a, np.float64) - b).max())
+        worst[0] = max(worst[0], d)
+        assert d <= 1e-5, err_msg
+
+    seen = replay_move(tr, make, lambda env: env.reset(static=True).cpu().numpy()[0], do_move, state_of, obs_cmp)
+    print(f"{name}: codes {seen.tolist()}, max obs err {worst[0]:.3g}")
+
+
+def test_move_lockstep_2048_envs_mixed_domains():
+    import torch
+    from oracle.ref_lib import RefEnv
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv
+    from reinforcementlearning4meshgeneration_amd.domains import boundary, random_domain
+    d1 = [tuple(p) for p in np.load(os.path.join(GOLDEN_DIR, "boundary16_biased_s2.npz"))["domain_xy"]]
+    doms = [boundary(0), boundary(-1), d1] + [random_domain(900 + k) for k in range(13)]
+    n, T = 2048, 120
+    env_domain = (np.arange(n) % len(doms)).astype(np.int32)
+    env = MeshVecEnv(doms, env_domain=env_domain, auto_reset=False)
+    refs = [RefEnv.from_points(doms[d]) for d in env_domain]
+    obs = env.reset(static=True).cpu().numpy()
+    obs_ref = np.stack([r.reset(static=True)[0] for r in refs])
+    np.testing.assert_array_equal(obs, obs_ref)
+    rng = np.random.default_rng(77)
+    codes = np.zeros(4, int)
+    valid = mism = 0
+    for t in range(T):
+        pts = np.stack([rng.uniform(0.05, 0.45, n), rng.uniform(0.2, 1.5, n)], axis=1)
+        typ = rng.uniform(0, 1, n)
+        o, d, c, code = [x.cpu().numpy() for x in env.move(torch.from_numpy(pts), torch.from_numpy(typ))]
+        reset_mask = np.zeros(n, np.uint8)
+        for k in range(n):
+            n_before = refs[k].scalars()["n_elem"]
+            o_r, d_r, c_r, code_r = refs[k].move(pts[k], typ[k])
+            assert code[k] == code_r, (t, k, code[k], code_r)
+            codes[code_r] += 1
+            if code_r != 2:
+                assert bool(d[k]) == d_r and bool(c[k]) == c_r, (t, k)
+            if code_r == 0:
+                diff = np.abs(o[k].astype(np.float64) - o_r).max()
+                assert diff <= 1e-5, (t, k, diff)
+                mism += int((o[k] != o_r).sum())
+            valid += refs[k].scalars()["n_elem"] > n_before
+            if d_r or code_r >= 2:
+                reset_mask[k] = 1
+                refs[k].reset(static=True)
+        if reset_mask.any():
+            env.reset(mask=torch.from_numpy(reset_mask), static=True)
+        if t % 30 == 29 or t == T - 1:
+            for k in rng.choice(n, 96, replace=False):
+                st = env.get_state(int(k))
+                ids, xy = refs[k].ring()
+                np.testing.assert_array_equal(st["ring_ids"], ids)
+                np.testing.assert_array_equal(st["ring_xy"], xy)
+                assert len(env.get_not_valid(int(k))) == refs[k].not_valid_count() and st["n_elem"] == refs[k].scalars()["n_elem"]
+                if st["ref_index"] >= 0:
+                    assert st["ref_id"] == refs[k].ref_id()
+    print("move lockstep: codes", codes.tolist(), "valid", valid, "obs entries differing", mism)
+    assert valid > 0.1 * n * T and codes[0] > 0 and codes[3] > 0 and mism <= 1e-6 * n * T * 18
+    env.close()
+
+
+def test_single_env_move_and_static_reset_follow_the_reference_surface():
+    from reinforcementlearning4meshgeneration_amd import BoudaryEnv
+    tr = dict(np.load(os.path.join(GOLDEN_DIR, "move_hexagon_s3.npz")))
+    env = BoudaryEnv([tuple(p) for p in tr["domain_xy"]])
+    plain = env.reset()
+    static = env.reset(static=True)
+    assert np.array_equal(static, tr["reset_obs"]) and static[1] == 0.0 and plain[1] == 1.0
+    assert np.array_equal(np.delete(plain, 1), np.delete(static, 1))
+    raised = 0
+    for t in range(len(tr["points"])):
+        if tr["code"][t] == 2:
+            with pytest.raises(UnboundLocalError):
+                env.move(tr["points"][t], tr["types"][t])
+            raised += 1
+        else:
+            obs, rew, done, info = env.move(list(tr["points"][t]), float(tr["types"][t]))
+            assert rew == 0 and isinstance(done, bool) and set(info) == {"is_complete"}
+            assert done == bool(tr["done"][t]) and info["is_complete"] == bool(tr["complete"][t])
+            assert (obs is None) == (tr["code"][t] != 0)
+            assert len(env.not_valid_points) == tr["n_not_valid"][t]
+        if tr["was_reset"][t]:
+            env.reset(static=True)
+    assert raised > 0
+    env.close()

@@ -69,19 +69,19 @@ def test_golden_covers_edge_cases():
 from conftest import move_golden_names  # noqa: E402
 
 
-def replay_move(tr, make_env, do_reset, do_move, state_of):
+def replay_move(tr, make_env, do_reset, do_move, state_of, obs_cmp=np.testing.assert_array_equal):
     """Shared by the oracle test (here) and the GPU test: replays a recorded move() trace through `do_move` and compares
     with what the reference returned.  codes: 0 ok, 1 obs None, 2 the reference raises, 3 it would smooth."""
     env = make_env(tr)
     obs = do_reset(env)
-    np.testing.assert_array_equal(obs, tr["reset_obs"])
+    obs_cmp(obs, tr["reset_obs"])
     seen = np.zeros(4, int)
     for t in range(len(tr["points"])):
         obs, done, comp, code = do_move(env, tr["points"][t], float(tr["types"][t]))
         assert code == tr["code"][t], (t, code, tr["code"][t])
         seen[code] += 1
         if code == 0:
-            np.testing.assert_array_equal(obs, tr["obs"][t], err_msg=f"obs move {t}")
+            obs_cmp(obs, tr["obs"][t], err_msg=f"obs move {t}")
         if code != 2:
             assert done == bool(tr["done"][t]) and comp == bool(tr["complete"][t]), t
         st = state_of(env)
