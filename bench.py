@@ -339,7 +339,7 @@ def main():
     traffic, traffic_src = pmc_traffic(n, args.workload)
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                       "kernel": ("meshenv::k_step_group<%d, true>" % env.group_size) if env.group_size > 1 else "meshenv::k_step<false, true>",
+                       "kernel": env.step_kernel,
                        "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": min_ms * 1e3,
                        "algorithmic_bytes_per_launch": alg, "launches_timed": n_timed, "timing": timing,
                        "instruction_side": instruction_side(n, args.workload, avg_ms * 1e3)}

@@ -112,6 +112,10 @@ int meshenv_max_ring(const MeshEnv *h);
 /* Environments per workgroup of the single-step kernel: 1 = k_step<false> (one wave per workgroup), 8 / 16 =
  * k_step_group<G> (chosen at creation from n_envs, see meshenv_create in csrc/meshenv_hip.hip). */
 int meshenv_group_size(const MeshEnv *h);
+/* Which single-step kernel meshenv_step launches: 0 = k_step<false> (one wave per workgroup), 1 = k_step_group<G>
+ * (checks, workgroup barrier, updates dealt over the SIMDs), 2 = k_step_spec<G> (no barrier: an action that survives the
+ * cheap exact tests is extracted speculatively by an idle wavefront while its checks finish). */
+int meshenv_step_kernel(const MeshEnv *h);
 
 /*
  * reset(): rl/boundary_env.py:67-84 for every env whose mask byte is non-zero (all envs when

@@ -39,7 +39,7 @@ EXPORTS = [
     "meshenv_counters", "meshenv_set_timing", "meshenv_kernel_times", "meshenv_selftest", "meshenv_set_packed_output",
     "meshenv_actor_create", "meshenv_actor_destroy", "meshenv_actor_set_stream", "meshenv_actor_load",
     "meshenv_actor_forward", "meshenv_actor_sample", "meshenv_get_last_episode", "meshenv_element_quality",
-    "meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid",
+    "meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid", "meshenv_step_kernel",
 ]
 
 
@@ -78,6 +78,8 @@ def load():
     L.meshenv_max_ring.argtypes = [vp]
     L.meshenv_group_size.argtypes = [vp]
     L.meshenv_group_size.restype = C.c_int
+    L.meshenv_step_kernel.argtypes = [vp]
+    L.meshenv_step_kernel.restype = C.c_int
     L.meshenv_reset.argtypes = [vp, u8p, f32p]
     L.meshenv_reset_static.argtypes = [vp, u8p, f32p, C.c_int]
     L.meshenv_move.argtypes = [vp, vp, vp, vp, vp, vp, vp]

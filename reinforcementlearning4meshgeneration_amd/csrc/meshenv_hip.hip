@@ -34,6 +34,7 @@ struct MeshEnv {
     bool default_params = true;  // geometry constants are the reference's: literal-constant kernel instantiations
     size_t lds = 0;
     int n_cu = 256;       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
+    bool spec = false;    // single-step kernel = k_step_spec (speculative extraction, no workgroup barrier)
     int group = 1;        // environments (wavefronts) per workgroup of the single-step kernel
     size_t group_lds = 0;
     std::vector<int32_t> dom_off_host, env_dom_host;
@@ -256,7 +257,18 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
         if (!h->default_params) G = 1;  // the group kernels exist with literal (default) geometry constants only
         h->group = G;
         h->group_lds = group_lds_bytes(cap, G);
-        if (G > 1 && h->group_lds > 64 * 1024) {
+        // The speculative form of the CU-group kernel (k_step_spec: two ring buffers per env, no workgroup barrier) is
+        // opt-in, MESHENV_SPEC=1: measured on MI355X at 4096 x boundary() it takes 16.7 us per launch against 15.5 us
+        // for the barrier + deal form (rocprofv3; DESIGN.md section 5 says why), so the default stays k_step_group.
+        const char *spec_env = getenv("MESHENV_SPEC");
+        h->spec = (G == 16 || G == 8) && spec_lds_bytes(cap, G) <= 150 * 1024 && spec_env && atoi(spec_env) == 1;
+        if (h->spec) {
+            h->group_lds = spec_lds_bytes(cap, G);
+            if (h->group_lds > 64 * 1024) {
+                const void *fn = G == 16 ? (const void *)k_step_spec<16, true> : (const void *)k_step_spec<8, true>;
+                CREATE_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+            }
+        } else if (G > 1 && h->group_lds > 64 * 1024) {
             const void *fn = G == 16 ? (const void *)k_step_group<16, true> : G == 8 ? (const void *)k_step_group<8, true> : (const void *)k_step_group<4, true>;
             CREATE_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         }
@@ -367,6 +379,7 @@ int meshenv_set_packed_output(MeshEnv *h, float *msg_dev)
 int meshenv_num_envs(const MeshEnv *h) { return h ? h->n_envs : MESHENV_E_ARG; }
 int meshenv_max_ring(const MeshEnv *h) { return h ? h->max_ring : MESHENV_E_ARG; }
 int meshenv_group_size(const MeshEnv *h) { return h ? h->group : MESHENV_E_ARG; }
+int meshenv_step_kernel(const MeshEnv *h) { return h ? (h->group > 1 ? (h->spec ? 2 : 1) : 0) : MESHENV_E_ARG; }
 
 int meshenv_reset_static(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev, int is_static)
 {
@@ -451,7 +464,9 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         A.step0 = (unsigned long long)h->steps_done;
         A.cap = h->cap;
         A.auto_reset = auto_reset;
-        if (G == 16) hipLaunchKernelGGL((k_step_group<16, true>), grid, block, h->group_lds, h->stream, A);
+        if (h->spec && G == 16) hipLaunchKernelGGL((k_step_spec<16, true>), grid, block, h->group_lds, h->stream, A);
+        else if (h->spec && G == 8) hipLaunchKernelGGL((k_step_spec<8, true>), grid, block, h->group_lds, h->stream, A);
+        else if (G == 16) hipLaunchKernelGGL((k_step_group<16, true>), grid, block, h->group_lds, h->stream, A);
         else if (G == 8) hipLaunchKernelGGL((k_step_group<8, true>), grid, block, h->group_lds, h->stream, A);
         else hipLaunchKernelGGL((k_step_group<4, true>), grid, block, h->group_lds, h->stream, A);
     } else {
@@ -653,6 +668,23 @@ int meshenv_counters(MeshEnv *h, uint64_t *out_host)
     out_host[3] = sv;
     return MESHENV_OK;
 }
+
+#ifdef MESHENV_SPEC_STATS
+// diagnostic build only: k_step_spec event counts / timestamps (reset = 1 clears them)
+int meshenv_debug_spec_stats(MeshEnv *h, uint64_t *count_host, uint64_t *time_host, int n_envs, int reset)
+{
+    if (!h) return MESHENV_E_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (count_host) HIP_TRY(h, hipMemcpyFromSymbol(count_host, HIP_SYMBOL(g_spec_count), sizeof(uint64_t) * 16));
+    if (time_host) HIP_TRY(h, hipMemcpyFromSymbol(time_host, HIP_SYMBOL(g_spec_time), sizeof(uint64_t) * 12 * (size_t)n_envs));
+    if (reset) {
+        static uint64_t zeros[65536 * 12];
+        HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(g_spec_count), zeros, sizeof(uint64_t) * 16));
+        HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(g_spec_time), zeros, sizeof(uint64_t) * 12 * 65536));
+    }
+    return MESHENV_OK;
+}
+#endif
 
 #ifdef MESHENV_STAMPS
 // diagnostic build only: raw per-env counter records (see k_step)

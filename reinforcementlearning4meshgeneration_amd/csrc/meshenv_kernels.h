@@ -36,6 +36,25 @@ constexpr int kStLogHalf = 16;  // which half of the element / vertex log the ru
 #define MESHENV_STAMP(c, k) do { } while (0)
 #endif
 
+#ifdef MESHENV_SPEC_STATS
+// diagnostic build only (tools/spec_stats.py): event counts and per-env timestamps (100 MHz ticks) of the last launch
+__device__ unsigned long long g_spec_count[16];
+__device__ unsigned long long g_spec_time[65536 * 12];
+#if MESHENV_SPEC_STATS == 2   // counts (global atomics: they distort the timeline, so timestamps come from a build of their own)
+#define SPEC_COUNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_spec_count[k], 1ULL); } while (0)
+#else
+#define SPEC_COUNT(k) do { } while (0)
+#endif
+#define SPEC_TIME(env, k) do { if ((threadIdx.x & 63) == 0 && (env) < 65536) g_spec_time[(size_t)(env) * 12 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SPEC_NOW() __builtin_amdgcn_s_memrealtime()
+#define SPEC_TIME_AT(env, k, t) do { if ((threadIdx.x & 63) == 0 && (env) < 65536) g_spec_time[(size_t)(env) * 12 + (k)] = (t); } while (0)
+#else
+#define SPEC_NOW() 0ULL
+#define SPEC_TIME_AT(env, k, t) do { (void)(t); } while (0)
+#define SPEC_COUNT(k) do { } while (0)
+#define SPEC_TIME(env, k) do { } while (0)
+#endif
+
 struct Scratch {
     double2 q[4];       // quad vertices
     double ang[4];      // quad corner angles
@@ -105,56 +124,83 @@ __device__ __forceinline__ void carve_lds(Ctx &c, void *smem, int cap)
 
 // ------------------------------------------------------------------------------------------ load / store
 
-__device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env)
+// What load_env requests from HBM, held in registers until it is written to LDS (k_step_spec puts its one workgroup barrier
+// between the two halves, so that the barrier overlaps the memory round trip).
+struct EnvLoad {
+    EnvScalars s;
+    double2 v_xy, w_xy;
+    double v_key, w_key;
+    int v_id, v_st, w_id, w_st;
+    float obs;
+};
+
+__device__ __forceinline__ EnvLoad load_env_issue(const DevState &S, int env)
 {
+    EnvLoad L;
     const int lane = lane_id();
-    c.lane = lane;
-    c.env = env;
-    c.base = (size_t)env * S.cap;
+    const size_t base = (size_t)env * S.cap;
     // everything below is independent: one HBM round trip
-    const EnvScalars s = S.scal[env];
+    L.s = S.scal[env];
     const int first = S.cap < 64 ? S.cap : 64;
     // per-env base pointers are wave-uniform (SGPR pairs); the lane index stays a 32-bit offset
-    const double2 *gxy = S.ring_xy + c.base;
-    const int32_t *gid = S.ring_id + c.base;
-    const double *gkey = S.ring_key + c.base;
-    const int32_t *gst = S.ring_stamp + c.base;
+    const double2 *gxy = S.ring_xy + base;
+    const int32_t *gid = S.ring_id + base;
+    const double *gkey = S.ring_key + base;
+    const int32_t *gst = S.ring_stamp + base;
     const unsigned ul = (unsigned)lane;
-    double2 v_xy = make_double2(0, 0), w_xy = make_double2(0, 0);
-    double v_key = 0, w_key = 0;
-    int v_id = 0, v_st = kNotCand, w_id = 0, w_st = kNotCand;
+    L.v_xy = make_double2(0, 0); L.w_xy = make_double2(0, 0);
+    L.v_key = 0; L.w_key = 0;
+    L.v_id = 0; L.v_st = kNotCand; L.w_id = 0; L.w_st = kNotCand;
     if (lane < first) {
-        v_xy = gxy[ul];
-        v_id = gid[ul];
-        v_key = gkey[ul];
-        v_st = gst[ul];
+        L.v_xy = gxy[ul];
+        L.v_id = gid[ul];
+        L.v_key = gkey[ul];
+        L.v_st = gst[ul];
     }
     // rings longer than 64: the second chunk is requested in the same burst, up to the ring STRIDE (known from the
     // kernel arguments) rather than the ring length (known only once the record has arrived) -- no second round trip
     const bool second = S.cap > 64 && (int)(64u + ul) < S.cap;
     if (second) {
-        w_xy = gxy[64u + ul];
-        w_id = gid[64u + ul];
-        w_key = gkey[64u + ul];
-        w_st = gst[64u + ul];
+        L.w_xy = gxy[64u + ul];
+        L.w_id = gid[64u + ul];
+        L.w_key = gkey[64u + ul];
+        L.w_st = gst[64u + ul];
     }
-    c.obs = lane < kObsDim ? S.obs_cache[(size_t)env * kObsDim + lane] : 0.0f;
+    L.obs = lane < kObsDim ? S.obs_cache[(size_t)env * kObsDim + lane] : 0.0f;
+    return L;
+}
+
+__device__ __forceinline__ void load_env_commit(Ctx &c, const DevState &S, int env, const EnvLoad &L)
+{
+    const int lane = lane_id();
+    c.lane = lane;
+    c.env = env;
+    c.base = (size_t)env * S.cap;
+    const EnvScalars &s = L.s;
+    const int first = S.cap < 64 ? S.cap : 64;
+    const double2 *gxy = S.ring_xy + c.base;
+    const int32_t *gid = S.ring_id + c.base;
+    const double *gkey = S.ring_key + c.base;
+    const int32_t *gst = S.ring_stamp + c.base;
+    const unsigned ul = (unsigned)lane;
+    const bool second = S.cap > 64 && (int)(64u + ul) < S.cap;
+    c.obs = L.obs;
     c.n = uniform_i32(s.n); c.ref = uniform_i32(s.ref); c.n_elem = uniform_i32(s.n_elem);
     c.failed = uniform_i32(s.failed); c.n_new = uniform_i32(s.n_new); c.counter = uniform_i32(s.counter);
     c.status = uniform_i32(s.status); c.dom = uniform_i32(s.dom);
     c.bl = uniform_f64(s.bl); c.area = uniform_f64(s.area); c.ct = uniform_f64(s.ct); c.st = uniform_f64(s.st);
     c.ring_dirty = false;
     if (lane < first) {
-        c.xy[lane] = v_xy;
-        c.id[lane] = v_id;
-        c.key[lane] = v_key;
-        c.stamp[lane] = v_st;
+        c.xy[lane] = L.v_xy;
+        c.id[lane] = L.v_id;
+        c.key[lane] = L.v_key;
+        c.stamp[lane] = L.v_st;
     }
     if (second) {
-        c.xy[64u + ul] = w_xy;
-        c.id[64u + ul] = w_id;
-        c.key[64u + ul] = w_key;
-        c.stamp[64u + ul] = w_st;
+        c.xy[64u + ul] = L.w_xy;
+        c.id[64u + ul] = L.w_id;
+        c.key[64u + ul] = L.w_key;
+        c.stamp[64u + ul] = L.w_st;
     }
     for (unsigned i = 128u + ul; i < (unsigned)c.n; i += 64u) {
         c.xy[i] = gxy[i];
@@ -163,6 +209,12 @@ __device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env)
         c.stamp[i] = gst[i];
     }
     wave_sync();
+}
+
+__device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env)
+{
+    const EnvLoad L = load_env_issue(S, env);
+    load_env_commit(c, S, env, L);
 }
 
 // ring arrays LDS -> HBM (slots [0, n))
@@ -659,8 +711,11 @@ __device__ __forceinline__ P2 vr_at(const Ctx &c, const VRing &r, int j)
 //                  lanes 12,13  boundary-quality angles (M:333-340 / M:400-407)          -> tmp[8..9]
 // pk = packed ring slots of ref_neighbors (4 x 16 bit... passed as four ints), bc0/bc1 = centres of the
 // boundary-quality angles on the post-update ring.
+// (no_reject: the speculative update wave of k_step_spec evaluates the job lanes only -- no validity decision, no
+// straddle jobs; a compile-time constant at each call)
 __device__ __forceinline__ bool quad_pass(Ctx &c, const Params &prm, const VRing &vr, int p0, int p1, int p2, int p3,
-                                          int bc0, int bc1, bool have_pre, double pre_qy, double pre_qx)
+                                          int bc0, int bc1, bool have_pre, double pre_qy, double pre_qx,
+                                          const bool no_reject = false)
 {
     const int lane = c.lane;
     const double2 *q = c.sc->q;
@@ -677,11 +732,11 @@ __device__ __forceinline__ bool quad_pass(Ctx &c, const Params &prm, const VRing
             const double2 a = q[lane], b = q[(lane + 1) & 3], d = q[(lane + 3) & 3];
             cw_terms(mkp(a.x, a.y), mkp(b.x, b.y), mkp(d.x, d.y), qy, qx);
         }
-        if (__ballot(!(qy < 0.0)) != 0ULL && prm.min_degree > 0.0 && prm.max_degree < kPi) return false;
+        if (!no_reject && __ballot(!(qy < 0.0)) != 0ULL && prm.min_degree > 0.0 && prm.max_degree < kPi) return false;
     }
     // (a) segments_crossed: is_cross(m0m1, m2m3) || is_cross(m0m3, m1m2); 4 independent straddles
     bool sres = false;
-    if (lane < 4) {
+    if (!no_reject && lane < 4) {
         // lane:        0        1        2        3
         // self    (m0,m1)  (m2,m3)  (m0,m3)  (m1,m2)
         // other   (m2,m3)  (m0,m1)  (m1,m2)  (m0,m3)
@@ -725,7 +780,7 @@ __device__ __forceinline__ bool quad_pass(Ctx &c, const Params &prm, const VRing
     }
     const bool any_bad = __ballot(bad) != 0ULL;
     wave_sync();
-    return !any_bad;
+    return no_reject || !any_bad;
 }
 
 // check_intersection_with_boundary, M:510-530, after the distance filter: `count` surviving ring vertices are in
@@ -822,6 +877,88 @@ __device__ __forceinline__ void log_quad(Ctx &c, const DevState &S, int g0, int 
     c.n_elem += 1;
 }
 
+// The quad of an action and the ring update_boundary (M:575-648) would leave behind, as slot arithmetic on the current
+// ring: a function of (rule / new vertex, reference slot, ring length) alone.
+struct QuadPlan {
+    int mp0, mp1, mp2, mp3, r;   // ring slots of the quad vertices (mp0 = -1: the new vertex), position of the reference vertex
+    int p0, p1, p2, p3;          // ref_neighbors as post-update ring slots
+    int t0, t1;                  // post-update slots of the kept quad vertices
+    int bc0, bc1;                // centres of the boundary-quality angles on the post-update ring
+    VRing vr;
+};
+
+__device__ __forceinline__ QuadPlan plan_quad(bool new_vertex, int rule, int index, int n, P2 new_point)
+{
+    QuadPlan q;
+    if (new_vertex) {  // [new, i-1, i, i+1], B:177-182
+        q.mp0 = -1; q.mp1 = wrapi(index - 1, n); q.mp2 = index; q.mp3 = wrapi(index + 1, n); q.r = 2;
+    } else if (rule == -1) {  // [i-1, i, i+1, i+2], B:147-153
+        q.mp0 = wrapi(index - 1, n); q.mp1 = index; q.mp2 = wrapi(index + 1, n); q.mp3 = wrapi(index + 2, n); q.r = 1;
+    } else {  // [i-2, i-1, i, i+1], B:156-162
+        q.mp0 = wrapi(index - 2, n); q.mp1 = wrapi(index - 1, n); q.mp2 = index; q.mp3 = wrapi(index + 1, n); q.r = 2;
+    }
+    q.vr.is_new = new_vertex;
+    q.vr.new_point = new_point;
+    q.t0 = 0; q.t1 = 0;
+    if (new_vertex) {
+        q.vr.n = n; q.vr.lo = index; q.vr.hi = -1;
+        q.p0 = wrapi(index + 1, n); q.p1 = wrapi(index - 1, n); q.p2 = wrapi(index + 2, n); q.p3 = wrapi(index - 2, n);
+        q.bc0 = wrapi(index + 1, n); q.bc1 = wrapi(index - 1, n);
+    } else {
+        q.vr.lo = q.mp1 < q.mp2 ? q.mp1 : q.mp2; q.vr.hi = q.mp1 < q.mp2 ? q.mp2 : q.mp1; q.vr.n = n - 2;
+        q.t0 = q.mp0 - (q.mp0 > q.vr.lo ? 1 : 0) - (q.mp0 > q.vr.hi ? 1 : 0);
+        q.t1 = q.mp3 - (q.mp3 > q.vr.lo ? 1 : 0) - (q.mp3 > q.vr.hi ? 1 : 0);
+        const int id = q.t0 > q.t1 ? q.t0 : q.t1, nn = n - 2;
+        q.p0 = wrapi(id, nn); q.p1 = wrapi(id - 1, nn); q.p2 = wrapi(id + 1, nn); q.p3 = wrapi(id - 2, nn);
+        q.bc0 = q.t0; q.bc1 = q.t1;
+    }
+    return q;
+}
+
+// k_step_spec: what the checking wavefront of an env posts (in LDS) once the action has survived the cheap exact tests,
+// so that another wavefront of the workgroup can run the extraction speculatively while the checks finish.
+struct alignas(16) SpecJob {
+    int state;        // 0 none / withdrawn, 1 posted, 2 claimed by an update wave
+    int verdict;      // 0 pending, 1 commit, 2 discard
+    int upd_done;     // update wave: the post-update ring (buffer B) is final, the reward may be computed from it
+    int helper_done;  // checking wave: the reward has been computed, an auto-reset may overwrite buffer B
+    int what;         // new_vertex | (rule + 1) << 1 | index << 3
+    int n;            // ring length
+    int env, pad;
+    double npx, npy;  // the candidate point
+};
+
+struct SpecHook {
+    SpecJob *job;               // this env's job record
+    int *n_nopost;              // workgroup counter of owners that can no longer post (the pollers' exit condition)
+    bool posted;
+    bool stale;                 // the posted quad is not the one the checks went on with (find_same_point hit)
+};
+
+__device__ __forceinline__ void spec_post(SpecHook *hk, const Ctx &c, bool new_vertex, int rule, int index, P2 new_point)
+{
+    SpecJob *j = hk->job;
+    if (c.lane == 0) {
+        // (everything else the update wave needs -- the env's 64-byte record and its work counters -- it reads from HBM,
+        // where they stay unchanged until a commit)
+        *(int4 *)&j->verdict = make_int4(0, 0, 0, (new_vertex ? 1 : 0) | ((rule + 1) << 1) | (index << 3));
+        j->n = c.n;
+        j->env = c.env;
+        *(double2 *)&j->npx = make_double2(new_point.x, new_point.y);
+    }
+    wave_sync();  // a wave's LDS stores complete in order: the record is in place before the flag
+    if (c.lane == 0) {
+        *(volatile int *)&j->state = 1;
+        atomicAdd(hk->n_nopost, 1);   // after the flag: a poller that sees the count also sees the post
+    }
+    hk->posted = true;
+    // from here on this wave is on the launch's critical path (nine posts in ten end in an extraction): it takes the SIMD's
+    // issue slots ahead of the waves that are still rejecting their actions (arbitration is by priority, then age)
+    __builtin_amdgcn_s_setprio(2);
+    SPEC_COUNT(0);
+    SPEC_TIME(c.env, 1);
+}
+
 struct StepResult {
     double reward;
     int done, complete;
@@ -849,9 +986,11 @@ struct Decision {
 // (pre_reject: evaluate the quad's corner test before the point-in-polygon pass; a compile-time constant at each call)
 // (is_move: the move() API, B:265-326 -- the point comes as (radius fraction, angle) Python floats in mv_r / mv_a, the
 // rule from mv_type against TYPE_THRESHOLD = 0.3, and there is no find_same_point; a compile-time constant per call)
+// (hook != nullptr: k_step_spec -- every quad takes the exact corner-sign test up front and, once it has passed, the
+// action is posted for a speculative update on another wavefront; a compile-time null everywhere else)
 __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a0, float a1, float a2, const bool pre_reject,
                                               const bool is_move = false, double mv_r = 0.0, double mv_a = 0.0,
-                                              double mv_type = 0.5)
+                                              double mv_type = 0.5, SpecHook *hook = nullptr)
 {
     const Params &prm = S.prm;
     const int lane = c.lane;
@@ -948,6 +1087,8 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
                     return d;
                 }
             }
+            // the new-vertex quad survived the corner test: hand it out before the point-in-polygon pass
+            if (hook && have_pre) spec_post(hook, c, true, 0, index, new_point);
         }
         const bool inside = point_inside(c, prm, new_point);
         MESHENV_STAMP(c, 2);
@@ -962,40 +1103,25 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
         f.max_dist = quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3));
         bool same;
         near_count = near_filter_pass(c, f, new_point, is_move ? 0.0 : prm.same_eps, same);
-        if (same) rule = -1;  // existing point: the rule -1 quad, B:168-175 (its own filter pass follows)
-        else { new_vertex = true; have_filter = true; }
+        if (same) {  // existing point: the rule -1 quad, B:168-175 (its own filter pass follows)
+            rule = -1;
+            if (hook) hook->stale = hook->posted;
+        } else {
+            new_vertex = true;
+            have_filter = true;
+        }
     }
     // (move(): a rejection changes the reference vertex without changing the ring, so the memo does not apply there)
     if (!is_move && !new_vertex && (c.status & (rule == -1 ? kStRm1Bad : kStRp1Bad))) {
         d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;  // B:248, outcome remembered from an earlier attempt on this state
         return d;
     }
-    if (new_vertex) {  // [new, i-1, i, i+1], B:177-182
-        mp0 = -1; mp1 = wrapi(index - 1, n); mp2 = index; mp3 = wrapi(index + 1, n); r = 2;
-    } else if (rule == -1) {  // [i-1, i, i+1, i+2], B:147-153
-        mp0 = wrapi(index - 1, n); mp1 = index; mp2 = wrapi(index + 1, n); mp3 = wrapi(index + 2, n); r = 1;
-    } else {  // [i-2, i-1, i, i+1], B:156-162
-        mp0 = wrapi(index - 2, n); mp1 = wrapi(index - 1, n); mp2 = index; mp3 = wrapi(index + 1, n); r = 2;
-    }
-    // the ring as update_boundary (M:575-648) would leave it, and the slots it touches
-    VRing vr;
-    vr.is_new = new_vertex;
-    vr.new_point = new_point;
-    int p0, p1, p2, p3;  // ref_neighbors as post-update ring slots
-    int t0 = 0, t1 = 0;  // post-update slots of the kept quad vertices
-    int bc0, bc1;
-    if (new_vertex) {
-        vr.n = n; vr.lo = index; vr.hi = -1;
-        p0 = wrapi(index + 1, n); p1 = wrapi(index - 1, n); p2 = wrapi(index + 2, n); p3 = wrapi(index - 2, n);
-        bc0 = wrapi(index + 1, n); bc1 = wrapi(index - 1, n);
-    } else {
-        vr.lo = mp1 < mp2 ? mp1 : mp2; vr.hi = mp1 < mp2 ? mp2 : mp1; vr.n = n - 2;
-        t0 = mp0 - (mp0 > vr.lo ? 1 : 0) - (mp0 > vr.hi ? 1 : 0);
-        t1 = mp3 - (mp3 > vr.lo ? 1 : 0) - (mp3 > vr.hi ? 1 : 0);
-        const int id = t0 > t1 ? t0 : t1, nn = n - 2;
-        p0 = wrapi(id, nn); p1 = wrapi(id - 1, nn); p2 = wrapi(id + 1, nn); p3 = wrapi(id - 2, nn);
-        bc0 = t0; bc1 = t1;
-    }
+    const QuadPlan qp = plan_quad(new_vertex, rule, index, n, new_point);
+    mp0 = qp.mp0; mp1 = qp.mp1; mp2 = qp.mp2; mp3 = qp.mp3; r = qp.r;
+    const VRing vr = qp.vr;
+    const int p0 = qp.p0, p1 = qp.p1, p2 = qp.p2, p3 = qp.p3;  // ref_neighbors as post-update ring slots
+    const int t0 = qp.t0, t1 = qp.t1;                          // post-update slots of the kept quad vertices
+    const int bc0 = qp.bc0, bc1 = qp.bc1;
     if (!(have_pre && new_vertex)) {  // (the early-rejection test of rule 0 has stored this very quad already)
         wave_sync();
         if (lane < 4) {
@@ -1005,7 +1131,25 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
         wave_sync();
     }
     MESHENV_STAMP(c, 3);
-    bool ok = quad_pass(c, prm, vr, p0, p1, p2, p3, bc0, bc1, have_pre && new_vertex, pre_qy, pre_qx);
+    bool pre_ok = have_pre && new_vertex;
+    if (hook && !hook->posted && !pre_ok && prm.min_degree > 0.0 && prm.max_degree < kPi) {
+        // rules -1 / +1: the corner-sign test of quad_pass (0), taken here so that the post comes right after it
+        double qy = -1.0, qx = 1.0;
+        if (lane < 4) {
+            const double2 *q = c.sc->q;
+            const double2 a = q[lane], b = q[(lane + 1) & 3], dd = q[(lane + 3) & 3];
+            cw_terms(mkp(a.x, a.y), mkp(b.x, b.y), mkp(dd.x, dd.y), qy, qx);
+        }
+        if (__ballot(lane < 4 && !(qy < 0.0)) != 0ULL) {
+            d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;  // B:248
+            if (!new_vertex) c.status |= (rule == -1 ? kStRm1Bad : kStRp1Bad);
+            return d;
+        }
+        pre_qy = qy; pre_qx = qx;
+        pre_ok = true;
+        spec_post(hook, c, new_vertex, rule, index, new_point);
+    }
+    bool ok = quad_pass(c, prm, vr, p0, p1, p2, p3, bc0, bc1, pre_ok, pre_qy, pre_qx);
     MESHENV_STAMP(c, 4);
     if (ok) {
         if (!have_filter) {  // rules -1 / +1 (and the same-point case): the filter pass on its own
@@ -1709,6 +1853,7 @@ k_step_group(GroupArgs A)
     Handoff *ho = (Handoff *)((char *)smem + (size_t)G * env_bytes);
     const int env = blockIdx.x * G + wave;
     const bool active = env < S.n_envs;
+    SPEC_TIME(env, 8);
     int pending = 0;
 #ifdef MESHENV_STAMPS
     // diagnostic build (tools/group_timeline.py, tools/group_phase2_timeline.py): dbg[env][0..5] describe the wave
@@ -1876,6 +2021,223 @@ k_step_group(GroupArgs A)
         }
     }
 #endif
+}
+
+
+// ------------------------------------------------------------------------------------------ speculative CU-group kernel
+
+
+__host__ __device__ __forceinline__ size_t spec_lds_bytes(int cap, int G)
+{
+    return (size_t)G * (2 * lds_bytes_for(cap) + sizeof(SpecJob)) + 64;  // + n_nopost, poller[4]
+}
+
+// bounded spin on an LDS word another wavefront of the workgroup sets (all waves of a workgroup are co-resident, so the
+// setter always runs; the bound only keeps a logic error from hanging the GPU)
+__device__ __forceinline__ int spin_until_nonzero(volatile int *w)
+{
+    int v = *w;
+    for (int it = 0; v == 0 && it < (1 << 22); it++) {
+        __builtin_amdgcn_s_sleep(1);
+        v = *w;
+    }
+    return v;
+}
+
+// The extraction of env slot e of the workgroup on a COPY (buffer B) of its ring, started while the checks of that env
+// still run on the original (buffer A): quad job lanes, ring update, candidate patch, next observation.  Nothing leaves
+// the wavefront before the checking wave's verdict; on "commit" this wave writes the step's results (everything but the
+// reward, which the checking wave computes from its own quad values and buffer B).
+template <bool kDefaultParams>
+__device__ __forceinline__ void spec_update(SpecJob *job, void *region_a, void *region_b, const DevState &S, int cap,
+                                            int auto_reset, unsigned long long step0)
+{
+    wave_sync();  // (compiler) nothing of the job record is read before the claim
+    __builtin_amdgcn_s_setprio(3);  // the extraction is the longest dependent chain of the launch
+    SPEC_COUNT(1);
+    SPEC_TIME(job->env, 2);
+    Ctx a, c;
+    carve_lds(a, region_a, cap);
+    carve_lds(c, region_b, cap);
+    c.lane = threadIdx.x & 63;
+    const int lane = c.lane;
+    c.env = uniform_i32(job->env);
+    c.base = (size_t)c.env * S.cap;
+    const EnvScalars rec = S.scal[c.env];      // requested now, consumed after the ring copy and the quad stage
+    const EnvCounters cnt0 = S.cnt[c.env];
+    c.n = uniform_i32(job->n);
+    c.ring_dirty = false;
+    c.obs = 0.0f;
+    const int n = c.n;
+    for (int i = lane; i < n; i += 64) {
+        c.xy[i] = a.xy[i];
+        c.key[i] = a.key[i];
+        c.stamp[i] = a.stamp[i];
+        c.id[i] = a.id[i];
+    }
+    const int what = uniform_i32(job->what);
+    const bool new_vertex = (what & 1) != 0;
+    const int rule = ((what >> 1) & 3) - 1, index = what >> 3;
+    const P2 new_point = mkp(uniform_f64(job->npx), uniform_f64(job->npy));
+    const QuadPlan qp = plan_quad(new_vertex, rule, index, n, new_point);
+    wave_sync();
+    if (lane < 4) {
+        const int mp = lane == 0 ? qp.mp0 : lane == 1 ? qp.mp1 : lane == 2 ? qp.mp2 : qp.mp3;
+        c.sc->q[lane] = mp < 0 ? make_double2(new_point.x, new_point.y) : c.xy[mp];
+    }
+    wave_sync();
+    quad_pass(c, S.prm, qp.vr, qp.p0, qp.p1, qp.p2, qp.p3, qp.bc0, qp.bc1, false, 0.0, 0.0, true);
+    if (*(volatile int *)&job->verdict == 2) { SPEC_COUNT(2); return; }
+    c.ref = uniform_i32(rec.ref); c.n_elem = uniform_i32(rec.n_elem); c.failed = uniform_i32(rec.failed);
+    c.n_new = uniform_i32(rec.n_new); c.counter = uniform_i32(rec.counter); c.status = uniform_i32(rec.status);
+    c.dom = uniform_i32(rec.dom);
+    c.bl = uniform_f64(rec.bl); c.area = uniform_f64(rec.area); c.ct = uniform_f64(rec.ct); c.st = uniform_f64(rec.st);
+    c.status &= ~(kStRm1Bad | kStRp1Bad);
+    Decision d;
+    d.ok = 1; d.new_vertex = new_vertex ? 1 : 0; d.index = index;
+    d.mp0 = qp.mp0; d.mp1 = qp.mp1; d.mp2 = qp.mp2; d.mp3 = qp.mp3;
+    d.p0 = qp.p0; d.p1 = qp.p1; d.p2 = qp.p2; d.p3 = qp.p3;
+    d.t0 = qp.t0; d.t1 = qp.t1; d.lo = qp.vr.lo; d.hi = qp.vr.hi;
+    d.done = 0; d.no_reference = 0; d.reward = 0.0;
+    d.new_point = new_point;
+    env_apply(c, S, d, &job->upd_done);
+    SPEC_TIME(c.env, 3);
+    const int verdict = spin_until_nonzero(&job->verdict);
+    if (verdict != 1) { SPEC_COUNT(3); return; }
+    SPEC_COUNT(4);
+    finish_and_store(c, S, d, cnt0, n, auto_reset, step0, &job->helper_done);
+    SPEC_TIME(c.env, 5);
+}
+
+// One step() of every env, G environments (wavefronts) per workgroup, one workgroup per CU, WITHOUT a workgroup barrier:
+//   * every wave runs the checks of its own env on the ring it staged in LDS (buffer A).  An action that survives the
+//     cheap exact tests (rule -1 / +1: not memoised as rejected, corner-sign test; new vertex: corner-sign test, before
+//     the point-in-polygon pass) is POSTED;
+//   * a wave whose own action has been rejected (88 % of them, most within 2-3 us) polls the workgroup's posts, claims one
+//     and runs that env's extraction speculatively on a copy of the ring (spec_update) while the owner's checks go on;
+//   * the owner's verdict commits or discards it.  On commit the update wave writes the state and the outputs, the owner
+//     computes the reward (from its own quad values and the updated copy).  A post nobody claimed is withdrawn by its
+//     owner, which then runs the extraction itself.
+// The dependent chain of a valid extraction is then  load + cheap tests + extraction  instead of  load + all checks +
+// barrier + extraction  (k_step_group), and no wave waits for the slowest check of its workgroup.
+template <int G, bool kDefaultParams>
+__global__ void __launch_bounds__(64 * G)
+k_step_spec(GroupArgs A)
+{
+    extern __shared__ double2 smem[];
+    DevState S = A.S;
+    const int cap = A.cap, auto_reset = A.auto_reset;
+    const float *__restrict__ actions = A.actions;
+    if (kDefaultParams) apply_default_params(S.prm);
+    const int wave = uniform_i32((int)(threadIdx.x >> 6));
+    const size_t env_bytes = lds_bytes_for(cap);
+    char *buf_a = (char *)smem, *buf_b = buf_a + (size_t)G * env_bytes;
+    SpecJob *jobs = (SpecJob *)(buf_b + (size_t)G * env_bytes);
+    volatile int *n_nopost = (volatile int *)(jobs + G);  // owners that have posted, or have finished without posting
+    const int env = blockIdx.x * G + wave;
+    const bool active = env < S.n_envs;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long t_entry = SPEC_NOW();
+    // This wave's state is requested from HBM first: nothing may precede these loads that the compiler would take for a
+    // store to global memory (an asm statement, with or without a memory clobber, is one) -- the wave-uniform loads (env
+    // record, counters, action) are only selected as scalar loads while the kernel is provably clean.
+    const int env_ld = active ? env : 0;
+    const float *a_ptr = actions + (size_t)env_ld * 3;
+    const float a0 = a_ptr[0], a1 = a_ptr[1], a2 = a_ptr[2];
+    const EnvCounters cnt0 = S.cnt[env_ld];
+    const EnvLoad ld = load_env_issue(S, env_ld);
+    if (threadIdx.x < G) {
+        *(volatile int *)&jobs[threadIdx.x].state = 0;
+        *(volatile int *)&jobs[threadIdx.x].verdict = 0;
+    }
+    if (threadIdx.x == 0) *n_nopost = 0;
+    // The job board is clean before anybody posts or polls: the only workgroup barrier, at t = 0.  In assembly, because
+    // __syncthreads() would also drain the vector loads just issued (lgkmcnt covers the LDS stores and the scalar loads,
+    // which return with the ring data anyway).
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    SPEC_TIME_AT(env, 8, t_entry);
+    SPEC_TIME(env, 9);
+
+    if (active) {
+        Ctx c;
+        carve_lds(c, buf_a + (size_t)wave * env_bytes, cap);
+        load_env_commit(c, S, env, ld);
+        const int n_before = c.n;
+        SPEC_TIME(env, 0);
+        SpecJob *job = jobs + wave;
+        SpecHook hook;
+        hook.job = job; hook.n_nopost = (int *)n_nopost; hook.posted = false; hook.stale = false;
+        Decision d = env_check(c, S, a0, a1, a2, true, false, 0.0, 0.0, 0.5, &hook);
+        // settle the post: 1 -> 0 withdraws it, 2 means an update wave is on it
+        bool claimed = false;
+        if (hook.posted) {
+            int old = 0;
+            if (lane == 0) old = atomicCAS((int *)&job->state, 1, 0);
+            claimed = uniform_i32(old) == 2;
+        }
+        const bool commit = claimed && d.ok && !hook.stale;
+        SPEC_TIME(env, 4);
+        if (d.ok) SPEC_COUNT(5);
+        if (d.ok && !commit) SPEC_COUNT(6);
+        if (claimed) {
+            wave_sync();
+            if (lane == 0) *(volatile int *)&job->verdict = commit ? 1 : 2;
+        }
+        if (!hook.posted && lane == 0) atomicAdd((int *)n_nopost, 1);
+        if (commit) {
+            // the reward, from this wave's quad values (scratch of buffer A) and the updated ring (buffer B)
+            Ctx cb;
+            carve_lds(cb, buf_b + (size_t)wave * env_bytes, cap);
+            cb.sc = c.sc;
+            cb.lane = lane;
+            const double rew = reward_on_helper(cb, S, d, n_before, c.dom, &job->upd_done);
+            wave_sync();
+            if (cb.n > 5) {  // not the end of the episode: the ring is final, written back here (off the update wave's path)
+                cb.env = env;
+                cb.base = (size_t)env * S.cap;
+                store_ring(cb, S);
+            }
+            if (lane == 0) {
+                *(volatile int *)&job->helper_done = 1;
+                const StepOuts o = late_outs();
+                o.reward[env] = rew;
+                if (S.msg) S.msg[(size_t)env * 21 + 18] = (float)rew;
+            }
+            SPEC_TIME(env, 7);
+        } else {
+            if (d.ok) env_apply(c, S, d);  // nobody took the post (or there was none): the extraction in place, as k_step does
+            finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0);
+            SPEC_TIME(env, 6);
+        }
+    } else if (lane == 0) {
+        atomicAdd((int *)n_nopost, 1);
+    }
+
+    __builtin_amdgcn_s_setprio(0);
+    // ---- this wave's own env is done: serve the workgroup's posts until no owner can post any more.  Every idle wave
+    //      polls, slowly (~1000 cycles apart: a poll costs issue slots of the SIMD's working waves); a dozen pollers out of
+    //      phase still pick a post up within a fraction of a microsecond.
+    for (int it = 0; it < (1 << 20); it++) {
+        const int settled = *n_nopost;  // read BEFORE the states: a post precedes its owner's count
+        int st = 0;
+        if (lane < G) st = *(volatile int *)&jobs[lane].state;
+        const unsigned posted = (unsigned)__ballot(st == 1);
+        if (posted != 0u) {
+            // spread the claimers: start looking at this wave's own slot
+            const unsigned rot = (posted >> wave) | (posted << (G - wave));
+            const int pick = (wave + (__ffs((int)(rot & ((1u << G) - 1u))) - 1)) % G;
+            int old = 0;
+            if (lane == 0) old = atomicCAS((int *)&jobs[pick].state, 1, 2);
+            if (uniform_i32(old) == 1) {
+                spec_update<kDefaultParams>(jobs + pick, buf_a + (size_t)pick * env_bytes, buf_b + (size_t)pick * env_bytes, S, cap,
+                                            auto_reset, A.step0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            continue;
+        }
+        if (settled >= G) break;  // no owner can post any more and nothing is posted
+        __builtin_amdgcn_s_sleep(15);  // ~960 cycles between polls
+    }
 }
 
 }  // namespace meshenv

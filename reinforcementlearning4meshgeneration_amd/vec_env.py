@@ -134,6 +134,8 @@ class MeshVecEnv:
             raise _capi.MeshEnvError(f"meshenv_create failed (code {rc}): {msg.decode() if msg else ''}")
         self.max_ring = self._L.meshenv_max_ring(self._handle)
         self.group_size = self._L.meshenv_group_size(self._handle)
+        self.step_kernel = {0: "meshenv::k_step<false, true>", 1: f"meshenv::k_step_group<{self.group_size}, true>",
+                            2: f"meshenv::k_step_spec<{self.group_size}, true>"}[self._L.meshenv_step_kernel(self._handle)]
         n = self.num_envs
         self.obs = torch.zeros((n, OBS_DIM), dtype=torch.float32, device=self.device)
         self.terminal_obs = torch.zeros((n, OBS_DIM), dtype=torch.float32, device=self.device)

@@ -231,3 +231,22 @@ def test_runtime_geometry_constants_instantiation(torch_cuda):
     assert torch_cuda.equal(r1, r2) and torch_cuda.equal(d1, d2)
     assert env.counters()["valid"] == ref_env.counters()["valid"] > 0
     env.close(); ref_env.close()
+
+
+def test_speculative_group_kernel_variant(torch_cuda, monkeypatch):
+    """k_step_spec (MESHENV_SPEC=1: an idle wavefront extracts the element speculatively while the owner's checks finish;
+    opt-in) against the oracle on the headline workload, and against the default kernel."""
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv, boundary
+    monkeypatch.setenv("MESHENV_SPEC", "1")
+    probe = MeshVecEnv([boundary(0)], n_envs=4096)
+    assert probe.step_kernel == "meshenv::k_step_spec<16, true>"
+    probe.close()
+    n, T = 4096, 96
+    rng = np.random.default_rng(21)
+    a = rng.uniform([-1, -1.5, 0], [1, 1.5, 1.5], size=(T, n, 3))
+    pick = rng.random((T, n)) < 0.5
+    b = np.stack([rng.uniform(-1, 1, (T, n)), rng.uniform(0.2, 1.0, (T, n)), rng.uniform(0.3, 1.2, (T, n))], axis=2)
+    a[pick] = b[pick]
+    st = _run_lockstep(torch_cuda, [boundary(0)], np.zeros(n, np.int32), a.astype(np.float32), check_every=24, sample=128)
+    print("spec kernel:", st)
+    assert st["valid"] > 0.1 * n * T and st["obs_mismatch"] <= 1e-6 * st["obs_total"]
