@@ -205,10 +205,12 @@ def main():
         doms = [golden_domain(x) for x in ("boundary16_biased_s2", "boundary15_biased_s5", "test1_biased_s42")]
         env_domain, wl, wl_short = np.arange(n, dtype=np.int32) % 3, "d1/d2/d3 interleaved (120/196/272-vertex rings)", "mixed d1/d2/d3"
     else:
-        from reinforcementlearning4meshgeneration_amd.domains import random_domain
-        doms = [random_domain(1000 + rank * n + k) for k in range(n)]
-        env_domain, wl, wl_short = np.arange(n, dtype=np.int32), "one random star-shaped ring per env (GenerateRandomPolygon restated, densified)", "GenerateRandomPolygon"
-    env = MeshVecEnv(doms, n_envs=n, env_domain=env_domain, device=local_rank, auto_reset=True, log_capacity=0)
+        doms = None   # generated on the device (meshenv_create_random); fetched back only for the CPU baseline leg
+        env_domain, wl, wl_short = np.arange(n, dtype=np.int32), "one GenerateRandomPolygon ring per env (ui/GenerateRandomPolygon.py:5-49 from random.Random(seed + k), clockwise, densified to 0.45, generated on the device)", "GenerateRandomPolygon"
+    if doms is None:
+        env = MeshVecEnv.from_random(n, 1000 + rank * n, device=local_rank, auto_reset=True, log_capacity=0)
+    else:
+        env = MeshVecEnv(doms, n_envs=n, env_domain=env_domain, device=local_rank, auto_reset=True, log_capacity=0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     lo = torch.tensor([-1.0, -1.5, 0.0], device=dev)
@@ -354,9 +356,10 @@ def main():
         torch.cuda.synchronize()
         out["fused_rollout"] = {"value": 3 * Tr * n / (time.perf_counter() - tr0), "unit": "env-steps/s", "steps_per_launch": Tr,
                                 "note": "meshenv_rollout: T consecutive steps per kernel launch, open-loop only"}
+    env_doms = env.domains if (doms is None and rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     env.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n, 99, doms, env_domain, wl)
+        out["cpu_baseline"] = cpu_baseline(n, 99, doms if doms is not None else env_doms, env_domain, wl)
         out["cpu_baseline"]["gpu_over_cpu_all_cores"] = value / out["cpu_baseline"]["all_cores"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -100,6 +100,26 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
                    const double *dom_consts_host, int n_envs, const int32_t *env_domain_host,
                    const MeshEnvParams *params, void *stream, MeshEnv **out);
 
+/*
+ * The same with one GENERATED domain per environment (BASELINE.json configs[4]: ui/GenerateRandomPolygon.py envs with
+ * variable vertex count): env k runs on the polygon of Python's random.Random(seed0 + k) --
+ *   generatePolygon(250, 250, 100, 0.55, 0.7, numVerts)   ui/GenerateRandomPolygon.py:5-49, 63 (numVerts = num_verts, or
+ *                                                         randint(8, 64) from the same stream when num_verts == 0)
+ *   consecutive duplicate pixels dropped, coordinates / 100 (general/polygon.py:110-117), made clockwise by the
+ *   drawing UI's rule (ui/tk-ui.py:84-101, 169-176), every edge split into ceil(length / edge) equal pieces with an even
+ *   vertex total, coordinates rounded to 4 places --
+ * generated, and its constants (poly_area, estimate_area_range) computed, on the device (csrc/meshenv_domgen.h); the host
+ * side is only a prefix sum over the ring lengths.  reinforcementlearning4meshgeneration_amd.domains.random_domain(seed)
+ * is the host restatement of the same ring (bit-identical; tests/test_gpu_domgen.py).  Fails with MESHENV_E_STATE if a
+ * polygon keeps fewer than 5 distinct pixels (the host function would draw another one from the stream).
+ */
+int meshenv_create_random(int device, int n_envs, uint64_t seed0, int num_verts, double edge, const MeshEnvParams *params,
+                          void *stream, MeshEnv **out);
+
+/* Host-side readout of one domain of the handle's table (synchronises the stream): xy_host[2*cap_points] receives the
+ * ring, *n_out its length, consts_host[3] (nullable) original_area, estimated_area_range[0]**2, [1]**2. */
+int meshenv_get_domain(MeshEnv *h, int domain, double *xy_host, int cap_points, int32_t *n_out, double *consts_host);
+
 void meshenv_destroy(MeshEnv *h);
 
 const char *meshenv_last_error(const MeshEnv *h);

@@ -40,6 +40,7 @@ EXPORTS = [
     "meshenv_actor_create", "meshenv_actor_destroy", "meshenv_actor_set_stream", "meshenv_actor_load",
     "meshenv_actor_forward", "meshenv_actor_sample", "meshenv_get_last_episode", "meshenv_element_quality",
     "meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid", "meshenv_step_kernel",
+    "meshenv_create_random", "meshenv_get_domain",
 ]
 
 
@@ -69,6 +70,11 @@ def load():
     L.meshenv_create.argtypes = [C.c_int, C.c_int, i32p, f64p, f64p, C.c_int, i32p, C.POINTER(MeshEnvParams), vp,
                                  C.POINTER(vp)]
     L.meshenv_create.restype = C.c_int
+    L.meshenv_create_random.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_double, C.POINTER(MeshEnvParams), vp,
+                                        C.POINTER(vp)]
+    L.meshenv_create_random.restype = C.c_int
+    L.meshenv_get_domain.argtypes = [vp, C.c_int, vp, C.c_int, i32p, vp]
+    L.meshenv_get_domain.restype = C.c_int
     L.meshenv_destroy.argtypes = [vp]
     L.meshenv_destroy.restype = None
     L.meshenv_last_error.argtypes = [vp]

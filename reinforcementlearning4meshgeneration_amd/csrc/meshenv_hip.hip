@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "meshenv_actor.h"
+#include "meshenv_domgen.h"
 #include "meshenv_kernels.h"
 #include "meshenv_quality.h"
 
@@ -147,13 +148,17 @@ void meshenv_destroy(MeshEnv *h)
     delete h;
 }
 
-int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, const double *dom_xy_host,
-                   const double *dom_consts_host, int n_envs, const int32_t *env_domain_host,
-                   const MeshEnvParams *params, void *stream, MeshEnv **out)
+}  // extern "C"
+
+// shared body of meshenv_create (domains from host arrays) and meshenv_create_random (gen != NULL: the rings and their
+// constants are produced on the device, csrc/meshenv_domgen.h; dom_xy_host / dom_consts_host are NULL then)
+static int create_impl(int device, int n_domains, const int32_t *dom_offsets_host, const double *dom_xy_host,
+                       const double *dom_consts_host, int n_envs, const int32_t *env_domain_host,
+                       const MeshEnvParams *params, void *stream, const GenParams *gen, MeshEnv **out)
 {
     if (!out) return fail_arg(nullptr, "meshenv_create: out is NULL");
     *out = nullptr;
-    if (n_domains <= 0 || n_envs <= 0 || !dom_offsets_host || !dom_xy_host || !dom_consts_host || !env_domain_host)
+    if (n_domains <= 0 || n_envs <= 0 || !dom_offsets_host || !env_domain_host || (!gen && (!dom_xy_host || !dom_consts_host)))
         return fail_arg(nullptr, "meshenv_create: null or empty input");
     MeshEnvParams prm;
     meshenv_default_params(&prm);
@@ -326,22 +331,44 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
     CREATE_TRY(dev_alloc(h, &S.dbg, (size_t)n_envs * 16));
 #endif
 
-    std::vector<DomConst> dc((size_t)n_domains);
-    std::memset(dc.data(), 0, dc.size() * sizeof(DomConst));
-    for (int d = 0; d < n_domains; d++) {
-        dc[d].orig_area = dom_consts_host[3 * d];
-        dc[d].min_area = dom_consts_host[3 * d + 1] * dom_consts_host[3 * d + 1];   // estimated_area_range[0] ** 2
-        dc[d].crit_area = dom_consts_host[3 * d + 2] * dom_consts_host[3 * d + 2];  // estimated_area_range[1] ** 2
-        dc[d].off = dom_offsets_host[d];
-        dc[d].n0 = dom_offsets_host[d + 1] - dom_offsets_host[d];
-        dc[d].ref = -1;
-    }
     std::vector<EnvScalars> sc((size_t)n_envs);
     std::memset(sc.data(), 0, sc.size() * sizeof(EnvScalars));
     for (int e = 0; e < n_envs; e++) sc[e].dom = env_domain_host[e];
 
-    CREATE_HIP(hipMemcpy(S.dom, dc.data(), sizeof(DomConst) * (size_t)n_domains, hipMemcpyHostToDevice));
-    CREATE_HIP(hipMemcpy(d_dom_xy, dom_xy_host, sizeof(double2) * (size_t)total_dom, hipMemcpyHostToDevice));
+    if (!gen) {
+        std::vector<DomConst> dc((size_t)n_domains);
+        std::memset(dc.data(), 0, dc.size() * sizeof(DomConst));
+        for (int d = 0; d < n_domains; d++) {
+            dc[d].orig_area = dom_consts_host[3 * d];
+            dc[d].min_area = dom_consts_host[3 * d + 1] * dom_consts_host[3 * d + 1];   // estimated_area_range[0] ** 2
+            dc[d].crit_area = dom_consts_host[3 * d + 2] * dom_consts_host[3 * d + 2];  // estimated_area_range[1] ** 2
+            dc[d].off = dom_offsets_host[d];
+            dc[d].n0 = dom_offsets_host[d + 1] - dom_offsets_host[d];
+            dc[d].ref = -1;
+        }
+        CREATE_HIP(hipMemcpy(S.dom, dc.data(), sizeof(DomConst) * (size_t)n_domains, hipMemcpyHostToDevice));
+        CREATE_HIP(hipMemcpy(d_dom_xy, dom_xy_host, sizeof(double2) * (size_t)total_dom, hipMemcpyHostToDevice));
+    } else {
+        // the rings at their offsets, then the constants: two launches, nothing generated on the host
+        int32_t *d_off = nullptr;
+        int *d_err = nullptr;
+        CREATE_TRY(dev_alloc(h, &d_off, (size_t)n_domains + 1));
+        CREATE_TRY(dev_alloc(h, &d_err, (size_t)1));
+        CREATE_HIP(hipMemcpy(d_off, dom_offsets_host, sizeof(int32_t) * ((size_t)n_domains + 1), hipMemcpyHostToDevice));
+        CREATE_HIP(hipMemset(d_err, 0, sizeof(int)));
+        hipLaunchKernelGGL(k_gen_rings, dim3(n_domains), dim3(64), 0, h->stream, *gen, n_domains, (const int32_t *)d_off, d_dom_xy, d_err);
+        CREATE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_dom_consts, dim3(n_domains), dim3(64), sizeof(double2) * (size_t)max_ring, h->stream, n_domains,
+                           (const int32_t *)d_off, (const double2 *)d_dom_xy, S.dom);
+        CREATE_HIP(hipGetLastError());
+        int err = 0;
+        CREATE_HIP(hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost));
+        if (err) {
+            g_create_error = "meshenv_create_random: a ring could not be generated on the device (fewer than 5 distinct pixels, or a length mismatch between the two passes)";
+            meshenv_destroy(h);
+            return MESHENV_E_STATE;
+        }
+    }
     CREATE_HIP(hipMemcpy(S.scal, sc.data(), sizeof(EnvScalars) * (size_t)n_envs, hipMemcpyHostToDevice));
     CREATE_HIP(hipMemset(S.ring_xy, 0, sizeof(double2) * total_env));
     CREATE_HIP(hipMemset(S.ring_id, 0, sizeof(int32_t) * total_env));
@@ -357,6 +384,88 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
 #undef CREATE_TRY
 #undef CREATE_HIP
     *out = h;
+    return MESHENV_OK;
+}
+
+extern "C" {
+
+int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, const double *dom_xy_host,
+                   const double *dom_consts_host, int n_envs, const int32_t *env_domain_host,
+                   const MeshEnvParams *params, void *stream, MeshEnv **out)
+{
+    return create_impl(device, n_domains, dom_offsets_host, dom_xy_host, dom_consts_host, n_envs, env_domain_host, params,
+                       stream, nullptr, out);
+}
+
+int meshenv_create_random(int device, int n_envs, uint64_t seed0, int num_verts, double edge, const MeshEnvParams *params,
+                          void *stream, MeshEnv **out)
+{
+    if (!out) return fail_arg(nullptr, "meshenv_create_random: out is NULL");
+    *out = nullptr;
+    if (n_envs <= 0 || !(edge > 0.0) || num_verts < 0 || (num_verts > 0 && (num_verts < 5 || num_verts > kGenMaxVerts)))
+        return fail_arg(nullptr, "meshenv_create_random: n_envs > 0, edge > 0 and num_verts in {0, 5..64} are required");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = "meshenv_create_random: no HIP device available (this library has no CPU fallback)";
+        return MESHENV_E_HIP;
+    }
+    if (device < 0 || device >= ndev) return fail_arg(nullptr, "meshenv_create_random: device index out of range");
+    GenParams gp;
+    gp.seed0 = seed0;
+    gp.ctr_x = 250; gp.ctr_y = 250; gp.ave_radius = 100; gp.irregularity = 0.55; gp.spikeyness = 0.7;  // GenerateRandomPolygon.py:63
+    gp.edge = edge;
+    gp.fixed_verts = num_verts;
+    // pass 1: the ring lengths (the domain table and the ring stride are sized from them)
+    std::vector<int32_t> offs((size_t)n_envs + 1, 0), env_dom((size_t)n_envs);
+    {
+        DeviceGuard guard(device);
+        if (guard.err != hipSuccess) { g_create_error = "meshenv_create_random: hipSetDevice failed"; return MESHENV_E_HIP; }
+        int32_t *d_cnt = nullptr;
+        int *d_err = nullptr;
+        bool ok = hipMalloc((void **)&d_cnt, sizeof(int32_t) * (size_t)n_envs) == hipSuccess &&
+                  hipMalloc((void **)&d_err, sizeof(int)) == hipSuccess && hipMemset(d_err, 0, sizeof(int)) == hipSuccess;
+        int err = 0;
+        if (ok) {
+            hipLaunchKernelGGL(k_gen_count, dim3(n_envs), dim3(64), 0, (hipStream_t)stream, gp, n_envs, d_cnt, d_err);
+            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
+                 hipMemcpy(offs.data() + 1, d_cnt, sizeof(int32_t) * (size_t)n_envs, hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        if (d_cnt) (void)hipFree(d_cnt);
+        if (d_err) (void)hipFree(d_err);
+        if (!ok) { g_create_error = "meshenv_create_random: the ring-length pass failed (HIP error)"; return MESHENV_E_HIP; }
+        if (err) { g_create_error = "meshenv_create_random: a ring could not be generated on the device (fewer than 5 distinct pixels)"; return MESHENV_E_STATE; }
+    }
+    for (int k = 0; k < n_envs; k++) {
+        if (offs[(size_t)k + 1] < 4) { g_create_error = "meshenv_create_random: empty ring"; return MESHENV_E_STATE; }
+        offs[(size_t)k + 1] += offs[(size_t)k];
+        env_dom[(size_t)k] = k;
+    }
+    return create_impl(device, n_envs, offs.data(), nullptr, nullptr, n_envs, env_dom.data(), params, stream, &gp, out);
+}
+
+int meshenv_get_domain(MeshEnv *h, int domain, double *xy_host, int cap_points, int32_t *n_out, double *consts_host)
+{
+    if (!h || !n_out) return MESHENV_E_ARG;
+    if (domain < 0 || domain >= h->n_domains) {
+        h->err = "meshenv_get_domain: domain out of range";
+        return MESHENV_E_RANGE;
+    }
+    MESHENV_ON_DEVICE(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int off = h->dom_off_host[(size_t)domain], n = h->dom_off_host[(size_t)domain + 1] - off;
+    *n_out = n;
+    if (xy_host) {
+        const int m = n < cap_points ? n : cap_points;
+        HIP_TRY(h, hipMemcpy(xy_host, h->cold.dom_xy + off, sizeof(double2) * (size_t)m, hipMemcpyDeviceToHost));
+    }
+    if (consts_host) {
+        DomConst dc;
+        HIP_TRY(h, hipMemcpy(&dc, h->S.dom + domain, sizeof(dc), hipMemcpyDeviceToHost));
+        consts_host[0] = dc.orig_area;
+        consts_host[1] = dc.min_area;    // estimated_area_range[0] ** 2
+        consts_host[2] = dc.crit_area;   // estimated_area_range[1] ** 2
+    }
     return MESHENV_OK;
 }
 

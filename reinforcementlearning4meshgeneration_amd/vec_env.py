@@ -132,6 +132,10 @@ class MeshVecEnv:
         if rc != 0:
             msg = self._L.meshenv_last_error(None)
             raise _capi.MeshEnvError(f"meshenv_create failed (code {rc}): {msg.decode() if msg else ''}")
+        self._finish_init()
+
+    def _finish_init(self):
+        torch = self._torch
         self.max_ring = self._L.meshenv_max_ring(self._handle)
         self.group_size = self._L.meshenv_group_size(self._handle)
         self.step_kernel = {0: "meshenv::k_step<false, true>", 1: f"meshenv::k_step_group<{self.group_size}, true>",
@@ -147,6 +151,72 @@ class MeshVecEnv:
         self._pending_actions = None
         self._closed = False
         self.reset()
+
+    @classmethod
+    def from_random(cls, n_envs: int, seed: int, device: int = 0, num_verts: int = 0, edge: float = 0.45,
+                    log_capacity: int = 0, auto_reset: bool = True, fail_limit: int = 100, lazy_infos: bool = True):
+        """n_envs environments, env k on its own GenerateRandomPolygon-style ring of ``random.Random(seed + k)``
+        (BASELINE.json configs[4]) -- generated, oriented, densified and measured ON THE DEVICE (meshenv_create_random);
+        ``domains.random_domain(seed + k)`` is the same ring computed on the host.  ``self.domains`` / ``self.constants``
+        are fetched from the device on first use."""
+        import torch
+        self = cls.__new__(cls)
+        self._torch = torch
+        self._L = _capi.load()
+        if not torch.cuda.is_available():
+            raise _capi.MeshEnvError("MeshVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                     "this package has no CPU fallback")
+        self.num_envs = int(n_envs)
+        self.device = torch.device("cuda", device)
+        self.auto_reset = bool(auto_reset)
+        self.lazy_infos = bool(lazy_infos)
+        self.log_capacity = int(log_capacity)
+        self.env_domain = np.arange(self.num_envs, dtype=np.int32)
+        self._domains = None
+        self._constants = None
+        prm = _capi.default_params()
+        prm.log_capacity = self.log_capacity
+        prm.fail_limit = int(fail_limit)
+        self._handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self._L.meshenv_create_random(device, self.num_envs, C.c_uint64(int(seed)), int(num_verts), float(edge),
+                                               C.byref(prm), C.c_void_p(stream), C.byref(self._handle))
+        if rc != 0:
+            msg = self._L.meshenv_last_error(None)
+            raise _capi.MeshEnvError(f"meshenv_create_random failed (code {rc}): {msg.decode() if msg else ''}")
+        self._finish_init()
+        return self
+
+    def get_domain(self, d: int):
+        """(ring [n, 2] float64, (original_area, est_min_l ** 2, est_crit_l ** 2)) of domain d as the device holds it."""
+        cap = self.max_ring
+        xy = np.zeros(2 * cap, np.float64)
+        n = C.c_int32(0)
+        consts = np.zeros(3, np.float64)
+        self._check(self._L.meshenv_get_domain(self._handle, int(d), xy.ctypes.data, cap, C.byref(n), consts.ctypes.data),
+                    "meshenv_get_domain")
+        return xy[:2 * n.value].reshape(-1, 2).copy(), tuple(float(c) for c in consts)
+
+    @property
+    def domains(self):
+        if self._domains is None:   # from_random: fetched from the device on demand
+            self._domains = [[tuple(p) for p in self.get_domain(d)[0]] for d in range(self.num_envs)]
+        return self._domains
+
+    @domains.setter
+    def domains(self, value):
+        self._domains = value
+
+    @property
+    def constants(self):
+        if self._constants is None:
+            self._constants = [domain_constants(d) for d in self.domains]
+        return self._constants
+
+    @constants.setter
+    def constants(self, value):
+        self._constants = value
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc, what):

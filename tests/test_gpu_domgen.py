@@ -1,0 +1,85 @@
+"""GPU: the domain pipeline on the device (BASELINE.json configs[4]): meshenv_create_random generates,
+orients, densifies and rounds one GenerateRandomPolygon-style ring per env from random.Random(seed + k) and computes
+its constants in HIP kernels.  Bar: the rings are BIT-IDENTICAL to the host restatement domains.random_domain(seed + k)
+(whose generator is pinned against the reference by tests/test_domains_cpu.py) for 8192 seeds; constants within 1e-12
+relative of the host's (BLAS dot / pow(x, 2) order effects); envs created this way step like envs created from the same
+rings through meshenv_create."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_rings_equal_host_restatement_8192_seeds():
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv
+    from reinforcementlearning4meshgeneration_amd.domains import domain_constants, random_domain
+    n, seed = 8192, 50_000
+    env = MeshVecEnv.from_random(n, seed)
+    sizes = []
+    worst = 0.0
+    for k in range(n):
+        ring, consts = env.get_domain(k)
+        host = random_domain(seed + k)
+        assert ring.shape == (len(host), 2), (k, ring.shape, len(host))
+        assert np.array_equal(ring, np.asarray(host, np.float64)), k          # bit for bit
+        sizes.append(len(host))
+        if k % 16 == 0:
+            c = domain_constants(host)
+            ref = np.array([c.original_area, c.est_min_l ** 2, c.est_crit_l ** 2])
+            rel = np.abs(np.array(consts) - ref) / ref
+            worst = max(worst, float(rel.max()))
+            assert rel.max() <= 1e-12, (k, consts, ref)
+    sizes = np.array(sizes)
+    print(f"device-generated rings: {n} identical to the host's, sizes {sizes.min()}..{sizes.max()} "
+          f"(mean {sizes.mean():.1f}), constants within {worst:.2e}")
+    assert len(np.unique(sizes)) > 20 and (sizes % 2 == 0).all()
+    assert env.max_ring == sizes.max()
+    env.close()
+
+
+@pytest.mark.parametrize("num_verts,seed", [(16, 7), (8, 2 ** 33 + 5), (64, 123456789)])
+def test_fixed_vertex_count_and_wide_seeds(num_verts, seed):
+    """numVerts fixed (the reference's own call uses 16) and seeds beyond 32 bits (two key words in init_by_array)."""
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv
+    from reinforcementlearning4meshgeneration_amd.domains import random_domain
+    env = MeshVecEnv.from_random(64, seed, num_verts=num_verts, edge=0.3)
+    for k in range(64):
+        ring, _ = env.get_domain(k)
+        host = random_domain(seed + k, num_verts=num_verts, edge=0.3)
+        assert np.array_equal(ring, np.asarray(host, np.float64)), k
+    env.close()
+
+
+def test_generated_envs_step_like_host_built_envs():
+    """Same rings through meshenv_create (host arrays) and meshenv_create_random (device): identical trajectories, and
+    both in lockstep with the oracle."""
+    import torch
+    from oracle.ref_lib import RefBatch, RefEnv
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv
+    from reinforcementlearning4meshgeneration_amd.domains import random_domain
+    n, seed, T = 1024, 900, 48
+    dev_env = MeshVecEnv.from_random(n, seed)
+    doms = [random_domain(seed + k) for k in range(n)]
+    host_env = MeshVecEnv(doms, env_domain=np.arange(n, dtype=np.int32))
+    refs = [RefEnv.from_points(d, cap_new=64) for d in doms]
+    batch = RefBatch(refs)
+    assert torch.equal(dev_env.reset(), host_env.reset())
+    assert np.array_equal(dev_env.obs.cpu().numpy(), batch.reset())
+    rng = np.random.default_rng(3)
+    a = rng.uniform([-1, -1.5, 0], [1, 1.5, 1.5], size=(T, n, 3))
+    pick = rng.random((T, n)) < 0.5
+    b = np.stack([rng.uniform(-1, 1, (T, n)), rng.uniform(0.2, 1.0, (T, n)), rng.uniform(0.3, 1.2, (T, n))], axis=2)
+    a[pick] = b[pick]
+    a = a.astype(np.float32)
+    acts = torch.from_numpy(a).cuda()
+    for t in range(T):
+        o1, r1, d1, c1 = dev_env.step(acts[t])
+        o2, r2, d2, c2 = host_env.step(acts[t])
+        o_ref, r_ref, d_ref, c_ref = batch.step(a[t], auto_reset=True, threads=8)
+        assert torch.equal(o1, o2) and torch.equal(d1, d2) and torch.equal(c1, c2), t
+        # the reward's speed term uses the area range, which the device computes with x * x where the host uses pow(x, 2)
+        assert float((r1 - r2).abs().max()) <= 1e-12, t
+        assert np.abs(o1.cpu().numpy().astype(np.float64) - o_ref).max() <= 1e-5 and np.array_equal(d1.cpu().numpy(), d_ref)
+        assert np.abs(r1.cpu().numpy() - r_ref).max() <= 1e-5
+    assert dev_env.counters()["valid"] == host_env.counters()["valid"] > 0
+    dev_env.close(); host_env.close()
