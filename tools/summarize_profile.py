@@ -28,7 +28,10 @@ def last_json_line(path):
 stats_csv = newest("trace/**/*_kernel_stats.csv")
 shutil.copy(stats_csv, os.path.join(dst, tag + "_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats_csv)))
-step = max((r for r in rows if "k_step" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
+# the one-step kernel the bench line names (the clock warm-up / pre-roll launches of the rollout kernel k_step<true, .> are
+# in the trace too)
+want = last_json_line(os.path.join(src, "bench.json"))["roofline"]["kernel"].replace(" ", "")
+step = max((r for r in rows if want in r["Name"].replace(" ", "")), key=lambda r: float(r["TotalDurationNs"]))
 kname = step["Name"].split("(")[0].replace("void ", "")
 
 
@@ -66,6 +69,7 @@ summary = {
                 "loads here mix 16/8/4-byte-per-lane widths, so the corrected figure is an upper bound and the raw one "
                 "a lower bound"},
     "n_envs_per_gpu": line["config"]["n_envs_per_gpu"],
+    "workload_key": "boundary0",
     "bench_line_under_rocprof": line_prof,
 }
 json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
