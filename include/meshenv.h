@@ -322,7 +322,8 @@ int meshenv_actor_sample(MeshActor *a, int n, const float *obs_dev, uint64_t see
  * back, so the parity tests can compare the device primitives with the oracle's one by one.
  *   what 0 round(python float, 4)   1 round(np.float64, 4)   2 Vertex.to_find_clockwise_angle (6 doubles: s, p1, p2)
  *        3 Segment.is_cross (8 doubles: a1, a2, b1, b2)  4 collinearity class, fast + 2*exact (2 doubles: c, d)
- *        5 round(np.float32, 4)      6 Point2D.distance_to (4 doubles)
+ *        5 round(np.float32, 4)      6 Point2D.distance_to (4 doubles)   7 sqrt_pos == sqrt (1 double)
+ *        8 quantised clockwise angle, fast form against exact (2 doubles: c, d): 0 equal, 1 guard band, 2 mismatch
  */
 int meshenv_selftest(int device, int what, int n, int in_per_item, const double *in_host, double *out_host);
 

@@ -61,6 +61,12 @@ def load():
         raise MeshEnvError(
             f"{path} is missing: build it with `python -m reinforcementlearning4meshgeneration_amd.build` "
             "(hipcc, gfx950).  This package has no CPU fallback.")
+    try:
+        # torch ships its own copy of the HIP runtime; loading it first makes this library bind to the same one (two
+        # runtimes in one process do not share the device: torch.cuda.is_available() turns False if ours initialises first)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp, i32p, f64p, u8p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p, C.c_void_p
     L.meshenv_default_params.argtypes = [C.POINTER(MeshEnvParams)]

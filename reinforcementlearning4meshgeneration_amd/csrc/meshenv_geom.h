@@ -16,6 +16,7 @@
 namespace meshenv {
 
 constexpr double kPi = 3.141592653589793;  // math.pi
+constexpr double kInfGeom = __builtin_huge_val();
 
 struct P2 {
     double x, y;
@@ -144,6 +145,51 @@ __device__ __forceinline__ double cw_finish(double t)
 {
     const double theta = -t;
     return round4_py(signbit(theta) ? 2 * kPi + theta : theta);
+}
+
+// cw_finish(atan2(c, d)) without the libm-grade atan2 (309 instructions): the result is quantised to 1e-4 rad, so an
+// angle known to 1e-12 decides the quantum everywhere except within a guard band of the rounding boundaries (k + 0.5) e-4,
+// where -- and for the degenerate inputs -- need_exact is raised and the caller evaluates the exact form.  ~50
+// instructions: |c|, |d| ordered, quotient by reciprocal + two Newton steps, reduction to |t| <= tan(pi/8), degree-7
+// polynomial in t^2 (max error 2.9e-13 on that interval, coefficients from a Chebyshev fit), quadrant and sign restored.
+// Identical to the exact form whenever need_exact is false (tests/test_gpu_primitives.py: 2e7 random + boundary cases).
+__device__ __forceinline__ double cw_fast(double c, double d, bool &need_exact)
+{
+    const double ax = fabs(d), ay = fabs(c);
+    const bool steep = ay > ax;
+    const double mx = steep ? ay : ax, mn = steep ? ax : ay;
+    double rc = __builtin_amdgcn_rcp(mx);
+    rc = fma(fma(-mx, rc, 1.0), rc, rc);
+    rc = fma(fma(-mx, rc, 1.0), rc, rc);
+    const double r = mn * rc;                       // in [0, 1]
+    const bool big = r > 0.41421356237309503;        // tan(pi / 8)
+    const double den = r + 1.0;
+    double rd = __builtin_amdgcn_rcp(den);
+    rd = fma(fma(-den, rd, 1.0), rd, rd);
+    rd = fma(fma(-den, rd, 1.0), rd, rd);
+    const double t = big ? (r - 1.0) * rd : r;       // atan(r) = pi / 4 + atan((r - 1) / (r + 1))
+    const double u = t * t;
+    double p = -0.03770173601926599;
+    p = fma(p, u, 0.069770051145731);
+    p = fma(p, u, -0.08993217256091926);
+    p = fma(p, u, 0.11103534914795694);
+    p = fma(p, u, -0.14285391259506042);
+    p = fma(p, u, 0.1999999318889726);
+    p = fma(p, u, -0.33333333278384714);
+    p = fma(p, u, 0.9999999999992708);
+    double a = t * p + (big ? 0.7853981633974483 : 0.0);
+    a = steep ? 1.5707963267948966 - a : a;
+    a = d < 0.0 ? kPi - a : a;
+    const double at = copysign(a, c);                // ~ atan2(c, d)
+    const double theta = -at;
+    const double ang = signbit(theta) ? 2 * kPi + theta : theta;
+    const double y = ang * 1e4;
+    const double f = floor(y);
+    const double fr = y - f;
+    // guard band 1e-5 quanta = 1e-9 rad around the rounding boundary (the fast angle is good to ~1e-12); zero, NaN and
+    // magnitudes outside [1e-290, 1e290] (reciprocal range) take the exact form
+    need_exact = !(mx > 1e-290) || !(mx < 1e290) || !(mn >= 0.0) || fabs(fr - 0.5) < 1e-5;
+    return div1e4(fr > 0.5 ? f + 1.0 : f);
 }
 
 // Vertex.to_find_clockwise_angle, C:91-100

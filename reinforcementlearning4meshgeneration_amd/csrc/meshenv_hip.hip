@@ -828,6 +828,12 @@ __global__ void k_selftest(int what, int n, const double *in, double *out)
     else if (what == 5) out[i] = (double)round4_npf((float)in[i]);
     else if (what == 6) out[i] = dist(mkp(in[4 * i], in[4 * i + 1]), mkp(in[4 * i + 2], in[4 * i + 3]));
     else if (what == 7) out[i] = (sqrt_pos(in[i]) == sqrt(in[i])) ? 1.0 : 0.0;  // against the compiler's IEEE sqrt
+    else if (what == 8) {  // cw_fast against the exact form: 0 equal, 1 guard band raised (and equal after the fallback), 2 MISMATCH
+        bool ne;
+        const double f = cw_fast(in[2 * i], in[2 * i + 1], ne);
+        const double e = cw_finish(atan2(in[2 * i], in[2 * i + 1]));
+        out[i] = ne ? 1.0 : ((f == e && signbit(f) == signbit(e)) ? 0.0 : 2.0);
+    }
 }
 
 int meshenv_selftest(int device, int what, int n, int in_per_item, const double *in_host, double *out_host)

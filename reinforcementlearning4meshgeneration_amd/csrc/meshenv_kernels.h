@@ -770,7 +770,15 @@ __device__ __forceinline__ bool quad_pass(Ctx &c, const Params &prm, const VRing
     }
     bool bad = false;
     if (lane < 14) {
+        // every angle of this stage is quantised before use: the fast form, the exact one for the whole stage when any
+        // lane sits in a guard band
+#ifdef MESHENV_NO_FILTERS
         const double a = cw_finish(atan2_nc(jy, jx));
+#else
+        bool need_exact;
+        double a = cw_fast(jy, jx, need_exact);
+        if (__ballot(need_exact) != 0ULL) a = cw_finish(atan2_nc(jy, jx));
+#endif
         if (lane < 4) {
             c.sc->ang[lane] = a;
             bad = a > prm.max_degree || a < prm.min_degree;

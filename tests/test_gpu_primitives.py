@@ -108,3 +108,42 @@ def test_trimmed_sqrt_is_the_ieee_sqrt():
     x = np.concatenate([x, k * k, np.nextafter(k * k, 0), np.nextafter(k * k, np.inf)])   # exact squares and neighbours
     got = _run(7, x)
     assert np.all(got == 1.0), np.flatnonzero(got != 1.0)[:10]
+
+
+def test_fast_quantised_angle_equals_the_exact_form():
+    """cw_fast (quad stage: reciprocal + degree-7 polynomial, ~50 instructions instead of atan2's 309) returns the
+    reference's quantised clockwise angle whenever it does not raise its guard flag, and raises it near every rounding
+    boundary and for degenerate inputs (the kernels then evaluate the exact form for the whole stage)."""
+    rng = np.random.default_rng(8)
+    n = 4_000_000
+    # cross / dot terms of random corner configurations on the 1e-4 grid and on integer grids, as the kernels form them
+    p = np.round(rng.uniform(-8, 14, (n, 6)), 4)
+    g = rng.integers(-3, 13, (n, 6)).astype(np.float64)
+    q = np.concatenate([p, g])
+    v1 = q[:, 2:4] - q[:, 0:2]
+    v2 = q[:, 4:6] - q[:, 0:2]
+    c = v1[:, 0] * v2[:, 1] - v1[:, 1] * v2[:, 0]
+    d = v1[:, 0] * v2[:, 0] + v1[:, 1] * v2[:, 1]
+    # angles AT the rounding boundaries (k + 0.5) e-4 and a few ulps / 1e-10 / 1e-7 rad to either side, every quadrant
+    k = rng.integers(0, 62832, 400_000)
+    off = rng.choice([0.0, 1e-16, -1e-16, 1e-13, -1e-13, 1e-10, -1e-10, 3e-9, -3e-9, 1e-7, -1e-7], len(k))
+    ang = (k + 0.5) * 1e-4 + off
+    scale = 10.0 ** rng.uniform(-6, 6, len(k))
+    cb, db = -np.sin(ang) * scale, np.cos(ang) * scale          # theta = -atan2(c, d) = ang
+    special = np.array([[0.0, 1.0], [-0.0, 1.0], [0.0, -1.0], [-0.0, -1.0], [0.0, 0.0], [-0.0, 0.0], [0.0, -0.0], [-0.0, -0.0],
+                        [1.0, 0.0], [-1.0, 0.0], [1.0, -0.0], [-1.0, -0.0], [1e-300, 1.0], [-1e-300, 1.0], [1e-300, -1.0],
+                        [1.0, 1.0], [-1.0, 1.0], [1.0, -1.0], [-1.0, -1.0], [np.inf, 1.0], [1.0, np.inf], [np.nan, 1.0],
+                        [1e300, 1e300], [1e-310, 1e-310], [5e-324, 1.0], [0.41421356237309503, 1.0], [1.0, 0.41421356237309503]])
+    items = np.concatenate([np.stack([c, d], axis=1), np.stack([cb, db], axis=1), special])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = np.concatenate([_run(8, items[i:i + 2_000_000]) for i in range(0, len(items), 2_000_000)])
+    assert not (out == 2.0).any(), items[np.flatnonzero(out == 2.0)[:10]]
+    # the guard band is narrow: on generic terms the exact form is needed 2e-5 of the time; integer grids add the
+    # degenerate (0, 0) terms of coincident points
+    assert (out[:n] == 1.0).mean() < 1e-4 and (out[n:2 * n] == 1.0).mean() < 2e-2
+    bnd = out[2 * n:2 * n + len(k)]
+    near = np.abs(off) <= 1e-10
+    assert (bnd[near] == 1.0).all()                          # ... and it does fire at the boundaries
+    assert (out[-len(special):][[4, 5, 6, 7]] == 1.0).all()  # atan2(0, 0) family -> exact form
