@@ -466,10 +466,19 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     const P2 add_v = ldp(c, bq_scan ? bqi : 0);
     // traversal positions stage A had no lane for (rings longer than 58): their clockwise angles in full 64-lane
     // passes of their own, so that a 120-vertex ring costs one more transcendental pass, not two
-    for (int o = kScanLanes + lane; o < n - 1; o += 64) {
+    for (int o0 = kScanLanes; o0 < n - 1; o0 += 64) {
+        const int o = o0 + lane;
+        const bool in = o < n - 1;
         double cc, dd;
-        cw_terms(ref, ldp(c, wrapi(idc - 1 - o, n)), right, cc, dd);
-        c.ang_ord[o] = cw_finish(atan2_nc(cc, dd));
+        cw_terms(ref, ldp(c, wrapi(idc - 1 - (in ? o : 0), n)), right, cc, dd);
+#ifdef MESHENV_NO_FILTERS
+        const double a = cw_finish(atan2_nc(cc, dd));
+#else
+        bool need_exact;   // all of these angles are quantised: fast form, exact for the pass when a lane sits in a guard band
+        double a = cw_fast(cc, dd, need_exact);
+        if (__ballot(need_exact && in) != 0ULL) a = cw_finish(atan2_nc(cc, dd));
+#endif
+        if (in) c.ang_ord[o] = a;
     }
     wave_sync();
     for (int base = 0; base < n; base += 64) {
