@@ -102,6 +102,18 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// bounded spin on an LDS word another wavefront of the workgroup sets (all waves of a workgroup are co-resident, so the
+// setter always runs; the bound only keeps a logic error from hanging the GPU)
+__device__ __forceinline__ int spin_until_nonzero(volatile int *w)
+{
+    int v = *w;
+    for (int it = 0; v == 0 && it < (1 << 22); it++) {
+        __builtin_amdgcn_s_sleep(1);
+        v = *w;
+    }
+    return v;
+}
+
 // Python list index wrap for i in [-n, 2n)
 __device__ __forceinline__ int wrapi(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
 
@@ -1364,7 +1376,7 @@ __device__ __forceinline__ double reward_on_helper(Ctx &c, const DevState &S, co
     if (min_area <= mesh_area && mesh_area < crit_area) speed = (mesh_area - crit_area) / (crit_area - min_area);
     else if (mesh_area < min_area) speed = -1.0;
 
-    while (*upd_done == 0) __builtin_amdgcn_s_sleep(1);  // the update wave sets it unconditionally
+    spin_until_nonzero(upd_done);  // the update wave sets it unconditionally (bounded: see spin_until_nonzero)
     wave_sync();
     const bool m1 = d.new_vertex != 0;
     const int n = m1 ? n_before : n_before - 2;
@@ -1826,7 +1838,7 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
         if (term_obs && c.lane < kObsDim) term_obs[(size_t)env * kObsDim + c.lane] = c.obs;
         if (auto_reset) {
             if (has_helper) {
-                while (*helper_done == 0) __builtin_amdgcn_s_sleep(1);  // the helper sets it unconditionally
+                spin_until_nonzero(helper_done);  // the helper sets it unconditionally
                 wave_sync();
             }
             reset_from_domain(c, S);
@@ -2047,18 +2059,6 @@ k_step_group(GroupArgs A)
 __host__ __device__ __forceinline__ size_t spec_lds_bytes(int cap, int G)
 {
     return (size_t)G * (2 * lds_bytes_for(cap) + sizeof(SpecJob)) + 64;  // + n_nopost, poller[4]
-}
-
-// bounded spin on an LDS word another wavefront of the workgroup sets (all waves of a workgroup are co-resident, so the
-// setter always runs; the bound only keeps a logic error from hanging the GPU)
-__device__ __forceinline__ int spin_until_nonzero(volatile int *w)
-{
-    int v = *w;
-    for (int it = 0; v == 0 && it < (1 << 22); it++) {
-        __builtin_amdgcn_s_sleep(1);
-        v = *w;
-    }
-    return v;
 }
 
 // The extraction of env slot e of the workgroup on a COPY (buffer B) of its ring, started while the checks of that env

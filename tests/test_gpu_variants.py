@@ -1,0 +1,63 @@
+"""GPU: the diagnostic / fallback builds of the library stay correct.
+  -DMESHENV_NO_HELPER   CU-group kernel with the reward on the update wave (no helper wavefront, no inter-wave LDS flags)
+  -DMESHENV_NO_FILTERS  kernels without the exactness-preserving shortcuts (reference evaluation everywhere: the exact
+                        atan2 instead of cw_fast, no collinearity shortcut, ...)
+Each variant is compiled here with hipcc (the GPU box has the same image) and run in a process of its own (MESHENV_LIB
+selects the library at load time) through a short lockstep with the oracle; the default library's outputs on the same
+actions must be identical to the variants' bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r"""
+import json, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from lockstep import run_lockstep
+from reinforcementlearning4meshgeneration_amd import MeshVecEnv, boundary
+n, T = 4096, 64
+rng = np.random.default_rng(31)
+a = rng.uniform([-1, -1.5, 0], [1, 1.5, 1.5], size=(T, n, 3))
+pick = rng.random((T, n)) < 0.5
+b = np.stack([rng.uniform(-1, 1, (T, n)), rng.uniform(0.2, 1.0, (T, n)), rng.uniform(0.3, 1.2, (T, n))], axis=2)
+a[pick] = b[pick]; a = a.astype(np.float32)
+st = run_lockstep(torch, [boundary(0)], np.zeros(n, np.int32), a, check_every=32, sample=64)
+env = MeshVecEnv([boundary(0)], n_envs=n); env.reset()
+acts = torch.from_numpy(a).cuda(); h = 0.0
+for t in range(T):
+    o, r, d, c = env.step(acts[t]); h += float(o.double().sum()) + float(r.sum()) + float(d.sum())
+print(json.dumps(dict(valid=st["valid"], obs_mismatch=st["obs_mismatch"], kernel=env.step_kernel, checksum=h)))
+"""
+
+
+def _build(name, flags):
+    out = os.path.join(ROOT, "build_variants", f"lib_{name}.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    from reinforcementlearning4meshgeneration_amd.build import CSRC, HIPCC_FLAGS, hipcc_path
+    subprocess.check_call([hipcc_path(), *HIPCC_FLAGS, *flags, "-o", out, os.path.join(CSRC, "meshenv_hip.hip")], cwd=CSRC)
+    return out
+
+
+def _run(lib):
+    env = dict(os.environ)
+    if lib:
+        env["MESHENV_LIB"] = lib
+    p = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_no_helper_and_no_filters_builds_agree_with_the_default_library():
+    base = _run(None)
+    assert base["kernel"] == "meshenv::k_step_group<16, true>" and base["valid"] > 0.1 * 4096 * 64
+    for name, flags in (("nohelper", ["-DMESHENV_NO_HELPER"]), ("nofilters", ["-DMESHENV_NO_FILTERS"])):
+        res = _run(_build(name, flags))
+        assert res["valid"] == base["valid"] and res["obs_mismatch"] == 0, (name, res)
+        assert res["checksum"] == base["checksum"], (name, res["checksum"], base["checksum"])
