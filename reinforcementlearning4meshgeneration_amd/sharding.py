@@ -78,6 +78,8 @@ class BucketExchange:
         self.buckets = [torch.zeros((self.steps, n_envs, MSG_DIM), dtype=torch.float32, device=device) for _ in range(2)]
         self.gathered = [torch.empty((self.world * self.steps, n_envs, MSG_DIM), dtype=torch.float32, device=gdev)
                          for _ in range(2)]
+        # device addresses of every slot, for callers that hand the pointer to the C-ABI themselves (bench.py's timed loop)
+        self._slot_ptr = [[int(self.buckets[b][k].data_ptr()) for k in range(self.steps)] for b in range(2)]
         self.works = [None, None]      # in-flight collective per bucket
         self.first_step = [None, None]  # first step of the bucket contents handed to that collective
         self.collectives = 0
@@ -100,6 +102,13 @@ class BucketExchange:
         if k == 0:
             self._retire(b)
         return self.buckets[b][k]
+
+    def slot_ptr(self, t: int) -> int:
+        """slot(t) as a raw device address (same retire-before-reuse rule)."""
+        b, k = self._bucket(t), t % self.steps
+        if k == 0:
+            self._retire(b)
+        return self._slot_ptr[b][k]
 
     def after_step(self, t: int):
         b, k = self._bucket(t), t % self.steps
