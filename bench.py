@@ -79,8 +79,9 @@ def instruction_side(n_envs, workload, launch_us):
                 "wait_frac": p["SQ_WAIT_ANY"] / cyc, "valu_active_frac": p["SQ_ACTIVE_INST_VALU"] / cyc,
                 "issue_stall_frac": p["SQ_WAIT_INST_ANY"] / cyc,
                 "valu_issue_floor_us": floor_us, "valu_issue_frac_of_launch": floor_us / launch_us if launch_us else None,
-                "bound": "dependent-issue latency of the waves that extract an element (wait_frac), not VALU issue rate "
-                         "and not HBM"}
+                "bound": "not HBM: the typical workgroup is bound by the dependent-issue latency of the ~12 % of waves that "
+                         "extract an element (wait_frac), the launch's slowest workgroups (5-7 extractions on one CU) by "
+                         "VALU issue (DESIGN.md section 5)"}
     except KeyError:
         return None
 
