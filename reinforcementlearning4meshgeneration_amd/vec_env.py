@@ -439,17 +439,40 @@ class MeshVecEnv:
     def step_async(self, actions):
         self._pending_actions = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, 3)
 
+    def _numpy_buffers(self):
+        """Pinned host staging for the numpy API: one upload (actions) and ONE download per step -- the step kernel writes
+        the packed (obs | reward | done | complete) message (meshenv_set_packed_output) and that [n, 21] float32 block is
+        what crosses PCIe, instead of four separate tensors."""
+        if getattr(self, "_np_msg_dev", None) is None:
+            t, n = self._torch, self.num_envs
+            self._np_act_host = t.empty((n, 3), dtype=t.float32, pin_memory=True)
+            self._np_act_dev = t.empty((n, 3), dtype=t.float32, device=self.device)
+            self._np_msg_dev = t.zeros((n, 21), dtype=t.float32, device=self.device)
+            self._np_msg_host = t.empty((n, 21), dtype=t.float32, pin_memory=True)
+            self._np_term_host = t.empty((n, OBS_DIM), dtype=t.float32, pin_memory=True)
+        return self._np_act_host, self._np_act_dev, self._np_msg_dev, self._np_msg_host
+
     def step_wait(self):
         t = self._torch
         if self._pending_actions is None:
             raise RuntimeError("step_wait() without step_async()")
-        act = t.from_numpy(self._pending_actions).to(self.device, non_blocking=False)
+        act_host, act_dev, msg_dev, msg_host = self._numpy_buffers()
+        act_host.numpy()[:] = self._pending_actions
         self._pending_actions = None
-        obs, rew, done, comp = self.step(act)
-        obs_np = obs.cpu().numpy()
-        rew_np = rew.cpu().numpy().astype(np.float32)
-        done_np = done.cpu().numpy().astype(bool)
-        comp_np = comp.cpu().numpy().astype(bool)
+        act_dev.copy_(act_host, non_blocking=True)
+        self.set_packed_output(msg_dev)
+        try:
+            self.step(act_dev)
+        finally:
+            self.set_packed_output(None)
+        msg_host.copy_(msg_dev, non_blocking=True)
+        self._np_term_host.copy_(self.terminal_obs, non_blocking=True)   # rows of finished envs are read below
+        t.cuda.current_stream(self.device).synchronize()
+        m = msg_host.numpy()
+        obs_np = m[:, :OBS_DIM].copy()
+        rew_np = m[:, 18].copy()            # float32((double) reward): what .astype(np.float32) of the float64 reward gives
+        done_np = m[:, 19] != 0
+        comp_np = m[:, 20] != 0
         infos = self._build_infos(done_np, comp_np)
         return obs_np, rew_np, done_np, infos
 
@@ -466,7 +489,7 @@ class MeshVecEnv:
         idx = np.nonzero(done_np)[0]
         if idx.size:
             infos = list(infos)
-            term = self.terminal_obs.cpu().numpy()
+            term = self._np_term_host.numpy()    # downloaded with the message, before the step's one synchronise
             for k in idx:
                 infos[k] = {"is_complete": bool(comp_np[k]), "terminal_observation": term[k].copy(),
                             "TimeLimit.truncated": not bool(comp_np[k])}
