@@ -317,6 +317,7 @@ class MeshVecEnv:
     def set_packed_output(self, msg):
         """msg: float32 CUDA tensor [n, 21] (or None) that every following step fills with
         (obs | reward | done | complete) -- the all_gather payload of the multi-GPU path."""
+        self._packed_user = msg
         if msg is None:
             self._check(self._L.meshenv_set_packed_output(self._handle, None), "meshenv_set_packed_output")
             return
@@ -460,11 +461,12 @@ class MeshVecEnv:
         act_host.numpy()[:] = self._pending_actions
         self._pending_actions = None
         act_dev.copy_(act_host, non_blocking=True)
+        user_msg = getattr(self, "_packed_user", None)   # a caller's own exchange buffer (multi-GPU path) is put back
         self.set_packed_output(msg_dev)
         try:
             self.step(act_dev)
         finally:
-            self.set_packed_output(None)
+            self.set_packed_output(user_msg)
         msg_host.copy_(msg_dev, non_blocking=True)
         self._np_term_host.copy_(self.terminal_obs, non_blocking=True)   # rows of finished envs are read below
         t.cuda.current_stream(self.device).synchronize()
