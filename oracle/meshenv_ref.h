@@ -10,6 +10,9 @@
  * bit-for-bit (obs, reward, topology, candidate list) against traces recorded
  * from the reference itself (oracle/gen_golden.py -> tests/golden/ npz files).
  *
+ * oracle/meshenv_cpu_shim.c exports the step()/reset()/move() entry points of include/meshenv.h
+ * under the same names over this restatement (libmeshenv_cpu.so, host pointers).
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product library (libmeshenv_hip.so) never links,
  * loads or calls anything declared here.

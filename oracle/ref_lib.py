@@ -23,7 +23,7 @@ _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "meshenv_ref.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libmeshenv_ref.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "all"])   # + libmeshenv_cpu.so (the meshenv_* names over the oracle)
     return _LIB_PATH
 
 

@@ -50,7 +50,7 @@ def test_no_cpu_fallback_without_gpu():
 def test_product_code_never_touches_the_oracle():
     """oracle/ is test infrastructure: nothing in the package may import, load or link it."""
     pkg = os.path.join(ROOT, "reinforcementlearning4meshgeneration_amd")
-    banned = re.compile(r"(from\s+oracle|import\s+oracle|libmeshenv_ref|meshenv_ref_|ref_lib|ref_harness)")
+    banned = re.compile(r"(from\s+oracle|import\s+oracle|libmeshenv_ref|libmeshenv_cpu|meshenv_ref_|ref_lib|ref_harness)")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".h", ".hip")):
