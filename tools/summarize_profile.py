@@ -30,7 +30,8 @@ shutil.copy(stats_csv, os.path.join(dst, tag + "_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats_csv)))
 # the one-step kernel the bench line names (the clock warm-up / pre-roll launches of the rollout kernel k_step<true, .> are
 # in the trace too)
-want = last_json_line(os.path.join(src, "bench.json"))["roofline"]["kernel"].replace(" ", "")
+have_clean = os.path.exists(os.path.join(src, "bench.json")) and os.path.getsize(os.path.join(src, "bench.json")) > 0
+want = last_json_line(os.path.join(src, "bench.json" if have_clean else "bench_under_rocprof.json"))["roofline"]["kernel"].replace(" ", "")
 step = max((r for r in rows if want in r["Name"].replace(" ", "")), key=lambda r: float(r["TotalDurationNs"]))
 kname = step["Name"].split("(")[0].replace("void ", "")
 
@@ -48,8 +49,14 @@ def pmc_means(sub):
 pmc = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
     pmc.update(pmc_means(sub))
+calib = None
+cpath = os.path.join(dst, tag + "_fetch_calibration.json")
+if os.path.exists(cpath):   # tools/calib_fetch.sh: what one counted FETCH_SIZE byte stands for in the step kernel's load mix
+    calib = json.load(open(cpath))["factor_bytes_per_counted_byte"]
 line_prof = last_json_line(os.path.join(src, "bench_under_rocprof.json"))
-line = last_json_line(os.path.join(src, "bench.json"))
+# (tools/profile_round.sh runs this script once on the GPU box BEFORE its clean bench run, so that the clean line's
+#  roofline.traffic / instruction_side come from this very profile; bench.json does not exist yet then)
+line = last_json_line(os.path.join(src, "bench.json")) if have_clean else line_prof
 summary = {
     "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline",
     "workload": line["config"]["workload"],
@@ -65,16 +72,20 @@ summary = {
     "hbm_traffic_bytes_per_launch": {
         "raw_(FETCH+WRITE)*1024": (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024,
         "gfx950_corrected_(2*FETCH+WRITE)*1024": (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024,
+        "calibrated_(f*FETCH+WRITE)*1024": ((calib * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024) if calib else None,
+        "fetch_calibration_factor": calib,
         "note": "MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of wide (16 B/lane) coalesced streams on gfx950; the ring "
                 "loads here mix 16/8/4-byte-per-lane widths, so the corrected figure is an upper bound and the raw one "
-                "a lower bound"},
+                "a lower bound; the calibrated figure uses the factor measured for exactly this load mix on a footprint "
+                "beyond every cache (tools/calib_fetch.sh -> profiles/<tag>_fetch_calibration.json)"},
     "n_envs_per_gpu": line["config"]["n_envs_per_gpu"],
     "workload_key": "boundary0",
     "bench_line_under_rocprof": line_prof,
 }
 json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
 # the clean bench line is re-read AFTER the summary exists so that its roofline.traffic comes from this very profile
-json.dump(line, open(os.path.join(dst, tag + "_bench_line.json"), "w"), indent=1)
+if have_clean:
+    json.dump(line, open(os.path.join(dst, tag + "_bench_line.json"), "w"), indent=1)
 ev = line["roofline"].get("kernel_avg_us")
 print(f"{kname}: rocprof avg {float(step['AverageNs']) / 1e3:.2f} us over {step['Calls']} launches; bench events {ev} us; "
       f"value {line['value']:.4g} {line['unit']}; traffic <= {summary['hbm_traffic_bytes_per_launch']['gfx950_corrected_(2*FETCH+WRITE)*1024'] / 1e6:.2f} MB/launch")
