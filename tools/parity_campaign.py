@@ -44,6 +44,49 @@ def campaign(label, doms, env_domain, T, seed, biased, threads=16):
     print(label, st, flush=True)
     env.close()
 
+def move_campaign(label, doms, env_domain, T, seed):
+    """move() API (rl/boundary_env.py:265-432) in lockstep with the oracle's meshenv_ref_move."""
+    n = len(env_domain)
+    env = MeshVecEnv(doms, env_domain=env_domain, auto_reset=False)
+    refs = [RefEnv.from_points(doms[d], cap_new=64) for d in env_domain]
+    obs = env.reset(static=True).cpu().numpy()
+    assert np.array_equal(obs, np.stack([r.reset(static=True)[0] for r in refs]))
+    rng = np.random.default_rng(seed)
+    st = dict(moves=0, codes=[0, 0, 0, 0], valid=0, obs_mis=0, max_obs=0.0, flag_mis=0, topo_checked=0, topo_bad=0)
+    t0 = time.time()
+    for t in range(T):
+        pts = np.stack([rng.uniform(0.05, 0.45, n), rng.uniform(0.2, 1.5, n)], axis=1)
+        typ = rng.uniform(0, 1, n)
+        o, d, c, code = [x.cpu().numpy() for x in env.move(torch.from_numpy(pts), torch.from_numpy(typ))]
+        mask = np.zeros(n, np.uint8)
+        for k in range(n):
+            ne0 = refs[k].scalars()["n_elem"]
+            o_r, d_r, c_r, code_r = refs[k].move(pts[k], typ[k])
+            st["codes"][code_r] += 1
+            bad = int(code[k] != code_r) + (int(bool(d[k]) != d_r) + int(bool(c[k]) != c_r) if code_r != 2 else 0)
+            st["flag_mis"] += bad
+            if code_r == 0:
+                st["obs_mis"] += int((o[k] != o_r).sum())
+                st["max_obs"] = max(st["max_obs"], float(np.abs(o[k].astype(np.float64) - o_r).max()))
+            st["valid"] += refs[k].scalars()["n_elem"] > ne0
+            if d_r or code_r >= 2:
+                mask[k] = 1
+                refs[k].reset(static=True)
+        st["moves"] += n
+        if mask.any():
+            env.reset(mask=torch.from_numpy(mask), static=True)
+        if t % 50 == 49 or t == T - 1:
+            for k in rng.choice(n, size=min(96, n), replace=False):
+                s = env.get_state(int(k)); ids, xy = refs[k].ring()
+                st["topo_checked"] += 1
+                if not (np.array_equal(s["ring_ids"], ids) and np.array_equal(s["ring_xy"], xy)
+                        and len(env.get_not_valid(int(k))) == refs[k].not_valid_count()):
+                    st["topo_bad"] += 1
+    st["seconds"] = round(time.time() - t0, 1)
+    print(label, st, flush=True)
+    env.close()
+
+
 if __name__ == "__main__":
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     campaign("boundary0 x4096 uniform", [boundary(0)], np.zeros(4096, np.int32), int(1000 * scale), 101, False)
@@ -52,3 +95,5 @@ if __name__ == "__main__":
     campaign("6 shipped domains x2046 biased", big, (np.arange(2046) % 6).astype(np.int32), int(300 * scale), 103, True)
     rnd = [random_domain(5000 + k) for k in range(1024)]
     campaign("1024 random polygons x4096 biased", rnd, (np.arange(4096) % 1024).astype(np.int32), int(400 * scale), 104, True)
+    mdoms = [boundary(0), boundary(-1), boundary(1), boundary(2)] + big + [random_domain(7000 + k) for k in range(22)]
+    move_campaign("move() x2048 on 32 domains", mdoms, (np.arange(2048) % len(mdoms)).astype(np.int32), int(60 * scale), 105)
