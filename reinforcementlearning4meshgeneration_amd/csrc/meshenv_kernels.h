@@ -1610,6 +1610,33 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime();
 #endif
+    if (!kMulti && (auto_reset & 2)) {
+        // Throughput regime (bit 1 of auto_reset, set by the host for >= 16 384 envs): the 64-byte record and the action
+        // alone decide a step whose rule -1 / +1 quad is memoised as rejected (~45 % of the steps of a random policy at
+        // steady state) -- such a wave never stages its ring: 28 n bytes and the whole load / LDS prologue saved, at the
+        // price of one more dependent round trip for the others (hidden by the other waves of the SIMD at this occupancy;
+        // at 4096 envs it would sit on the critical path, so the latency kernels do not do this).  Same values as the full
+        // path: reward -1 / n_elem (B:248), failed_num + 1, the cached observation of the unchanged state.
+        const EnvScalars s0 = S.scal[env];
+        const int lane0 = lane_id();
+        const float ob = lane0 < kObsDim ? S.obs_cache[(size_t)env * kObsDim + lane0] : 0.0f;
+        const int st0 = uniform_i32(s0.status), failed0 = uniform_i32(s0.failed) + 1, ne0 = uniform_i32(s0.n_elem);
+        const bool memo = (a0 <= -0.5f && (st0 & kStRm1Bad) != 0) || (a0 >= 0.5f && (st0 & kStRp1Bad) != 0);
+        if (memo && uniform_i32(s0.ref) >= 0 && uniform_i32(s0.n) > 5 && failed0 < S.prm.fail_limit) {
+            const double rw = ne0 ? -1.0 / ne0 : -1.0;
+            if (lane0 < kObsDim) obs_out[(size_t)env * kObsDim + lane0] = ob;
+            if (S.msg && lane0 < 21)
+                S.msg[(size_t)env * 21 + lane0] = lane0 < kObsDim ? ob : (lane0 == 18 ? (float)rw : (lane0 == 19 ? 0.0f : 1.0f));
+            if (lane0 == 0) {
+                reward[env] = rw;
+                done[env] = 0;
+                complete[env] = 1;
+                S.scal[env].failed = failed0;
+            }
+            return;
+        }
+    }
+    auto_reset &= 1;
 #ifndef MESHENV_STAMPS
     const EnvCounters cnt0 = S.cnt[env];  // requested with the rest of the state: no round trip at the end
 #endif

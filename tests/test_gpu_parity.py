@@ -250,3 +250,35 @@ def test_speculative_group_kernel_variant(torch_cuda, monkeypatch):
     st = _run_lockstep(torch_cuda, [boundary(0)], np.zeros(n, np.int32), a.astype(np.float32), check_every=24, sample=128)
     print("spec kernel:", st)
     assert st["valid"] > 0.1 * n * T and st["obs_mismatch"] <= 1e-6 * st["obs_total"]
+
+
+def test_record_first_staging_equals_full_staging(torch_cuda, monkeypatch):
+    """Throughput regime (>= 8192 envs): a step whose rule -1 / +1 quad is memoised as rejected is answered from the
+    64-byte record alone, without staging the ring (MESHENV_LAZY overrides the size rule).  Outputs and state must be
+    bit-identical to the full path, step by step, including the 100-failure truncations that path has to leave alone."""
+    torch = torch_cuda
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv, boundary, random_domain
+    doms = [boundary(0), boundary(-1)] + [random_domain(300 + k) for k in range(6)]
+    n, T = 16384, 260          # long enough for envs to reach failed_num = 100
+    env_domain = (np.arange(n) % len(doms)).astype(np.int32)
+    full = MeshVecEnv(doms, env_domain=env_domain)
+    lazy = MeshVecEnv(doms, env_domain=env_domain)
+    assert full.step_kernel == "meshenv::k_step<false, true>"
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    lo = torch.tensor([-1.0, -1.5, 0.0], device="cuda"); hi = torch.tensor([1.0, 1.5, 1.5], device="cuda")
+    truncated = 0
+    for t in range(T):
+        a = (lo + (hi - lo) * torch.rand((n, 3), device="cuda", generator=g)).contiguous()
+        monkeypatch.setenv("MESHENV_LAZY", "0")
+        o1, r1, d1, c1 = [x.clone() for x in full.step(a)]
+        monkeypatch.setenv("MESHENV_LAZY", "1")
+        o2, r2, d2, c2 = lazy.step(a)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(c1, c2), t
+        truncated += int(((d1 != 0) & (c1 == 0)).sum())
+    assert truncated > 0
+    c_full, c_lazy = full.counters(), lazy.counters()
+    assert c_full == c_lazy and c_full["valid"] > 0
+    for k in range(0, n, 997):
+        s1, s2 = full.get_state(k), lazy.get_state(k)
+        assert s1["failed_num"] == s2["failed_num"] and np.array_equal(s1["ring_ids"], s2["ring_ids"]) and s1["n_elem"] == s2["n_elem"]
+    full.close(); lazy.close()
