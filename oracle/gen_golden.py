@@ -197,6 +197,23 @@ MOVE_TRACES = [
 ]
 
 
+# (fixture name, domain, seed, T, smooth after every k-th accepted element, iteration cap)
+SMOOTH_TRACES = [
+    ("smooth_boundary0_s1", "boundary0", 1, 600, 3, 400),
+    ("smooth_boundary0_s8", "boundary0", 8, 500, 2, 5),      # the iteration cap ends the sweeps, not the 0.001 rule
+    ("smooth_boundary16_s2", "boundary16", 2, 400, 4, 400),
+    ("smooth_random1_1_s3", "random1_1", 3, 400, 3, 400),
+]
+
+
+def main_smooth():
+    for name, dom, seed, T, every, iteration in SMOOTH_TRACES:
+        tr = H.record_smooth_trace(H.domain_points(dom), H.biased_actions(seed, T), every, iteration=iteration, max_v=4096)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **tr)
+        print(f"{name}: {T} steps, {int(tr['valid'].sum())} valid, {int(tr['n_calls'])} smooth_pave calls, sweeps "
+              f"{tr['call_sweeps'].tolist() if tr['n_calls'] else []}")
+
+
 def main_move():
     for name, dom, seed, T, reset_on_done in MOVE_TRACES:
         pts = H.domain_points(dom) if isinstance(dom, str) else dom
@@ -209,6 +226,9 @@ def main_move():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--smooth-only" in sys.argv:
+        main_smooth()
+        return
     if "--quality-only" in sys.argv:
         quality_fixture()
         return
@@ -224,6 +244,7 @@ def main():
     pts, acts = targeted_trace()
     save("boundary0_targeted", H.record_trace(pts, acts))
     main_move()
+    main_smooth()
 
 
 if __name__ == "__main__":

@@ -893,6 +893,80 @@ int meshenv_ref_move(RefEnv *e, const double *point, double type, float *obs, ui
     return rc;
 }
 
+/* ------------------------------------------------- smoothing: smooth_pave(..., interior=True)
+ *
+ * general/mesh.py:790-795 with interior=True: smooth_fixed_vertices (M:1258-1288) over the vertices of boundary.vertices
+ * that are not on the current front, then find_reference_candidates(target_angle=0).  The reference walks the
+ * Vertex.segments graph; here the graph is rebuilt from the element log:
+ *   - only generated vertices move (`if vertex in self.original_vertices: continue`), and a generated vertex receives
+ *     segments only from Mesh.connect_vertices (C:832-837) of the elements that contain it: for i = 0..3 the pair
+ *     (vertices[i], vertices[i-1]) gets a new Segment unless one exists already, appended to both ends' lists;
+ *   - get_connected_vertices (C:115-124) lists the other end of every segment in list order, so the neighbours of a
+ *     generated vertex are the partners of those pairs in element order, first occurrence only.
+ * The sweep is Gauss-Seidel in boundary.vertices order (domain ring first, generated vertices in creation order): every
+ * vertex sees the new position of its predecessors; x accumulates (neighbour.x + vertex.x) term by term from an int 0;
+ * the stop rule compares the running sum of the moved vertices' x + y with the previous sweep's (<= 0.001) or stops
+ * after `iteration` sweeps.  Returns 0, or -1 when the element / vertex log overflowed (graph incomplete) or a vertex
+ * has more than MESHENV_REF_MAX_DEG neighbours. */
+#define MESHENV_REF_MAX_DEG 16
+int meshenv_ref_smooth_interior(RefEnv *e, int iteration, int32_t *sweeps_out, double *diff_out)
+{
+    if (e->n_elem > e->cap_e || e->n_vert > e->cap_v) return -1;
+    const int nv = e->n_vert, n_new = nv - e->n0;
+    int32_t *adj = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_new > 0 ? n_new : 1) * MESHENV_REF_MAX_DEG);
+    int32_t *deg = (int32_t *)calloc((size_t)(n_new > 0 ? n_new : 1), sizeof(int32_t));
+    uint8_t *on_front = (uint8_t *)calloc((size_t)nv, 1);
+    int rc = 0;
+    for (int k = 0; k < e->n_elem && rc == 0; k++) {
+        const int32_t *q = e->quads + 4 * k;
+        for (int i = 0; i < 4 && rc == 0; i++) {
+            const int32_t a = q[i], b = q[(i + 3) & 3];
+            /* has_segment_with_vertex is symmetric (a segment sits in both ends' lists): test on a generated end */
+            const int32_t g = a >= e->n0 ? a : b, o = a >= e->n0 ? b : a;
+            if (g < e->n0) continue; /* two domain vertices: their lists are never read */
+            int found = 0;
+            for (int j = 0; j < deg[g - e->n0]; j++) found |= adj[(g - e->n0) * MESHENV_REF_MAX_DEG + j] == o;
+            if (found) continue;
+            const int32_t ends[2] = {a, b};
+            for (int s = 0; s < 2; s++) {
+                const int32_t v = ends[s], w = ends[1 - s];
+                if (v < e->n0) continue;
+                if (deg[v - e->n0] >= MESHENV_REF_MAX_DEG) { rc = -1; break; }
+                adj[(v - e->n0) * MESHENV_REF_MAX_DEG + deg[v - e->n0]++] = w;
+            }
+        }
+    }
+    for (int i = 0; i < e->n; i++) on_front[e->rid[i]] = 1;
+    double sum_coordinates = 0.0, diffs = 100.0;
+    int it = 0;
+    while (rc == 0 && diffs > 0.001 && it < iteration) {
+        it += 1;
+        double new_sum = 0.0;
+        for (int v = e->n0; v < nv; v++) {
+            if (on_front[v]) continue;
+            const int d = deg[v - e->n0];
+            if (d == 0) continue;
+            double x = 0.0, y = 0.0;
+            for (int j = 0; j < d; j++) {
+                const P2 c = e->vtab[adj[(v - e->n0) * MESHENV_REF_MAX_DEG + j]];
+                x += c.x + e->vtab[v].x;
+                y += c.y + e->vtab[v].y;
+            }
+            e->vtab[v].x = x / (double)(2 * d);
+            e->vtab[v].y = y / (double)(2 * d);
+            new_sum += e->vtab[v].x + e->vtab[v].y;
+        }
+        diffs = fabs(new_sum - sum_coordinates);
+        sum_coordinates = new_sum;
+    }
+    free(adj); free(deg); free(on_front);
+    if (rc != 0) return rc;
+    find_reference_candidates(e); /* M:795; the point environment (reference vertex, observation) is left as it was */
+    if (sweeps_out) *sweeps_out = it;
+    if (diff_out) *diff_out = diffs;
+    return 0;
+}
+
 int meshenv_ref_not_valid_count(const RefEnv *e) { return e->n_nv; }
 
 int meshenv_ref_ring_len(const RefEnv *e) { return e->n; }

@@ -57,6 +57,9 @@ int meshenv_ref_not_valid_count(const RefEnv *e);
 /* state readout for parity tests */
 int meshenv_ref_ring_len(const RefEnv *e);
 void meshenv_ref_get_ring(const RefEnv *e, int32_t *ids, double *xy);
+/* smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=..., interior=True), general/mesh.py:790-795:
+ * Gauss-Seidel relaxation of the generated vertices off the front + candidate list rebuilt; -1 = log overflow */
+int meshenv_ref_smooth_interior(RefEnv *e, int iteration, int32_t *sweeps_out, double *diff_out);
 /* candidate list in the reference's list order: (key asc, insertion desc) */
 int meshenv_ref_get_candidates(const RefEnv *e, int32_t *ids, double *keys);
 int meshenv_ref_ref_id(const RefEnv *e);

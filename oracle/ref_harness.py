@@ -280,3 +280,94 @@ def record_move_trace(points, pts: np.ndarray, types: np.ndarray, static_reset: 
                consts=np.array([float(env.original_area), float(env.average_edge_length),
                                 float(env.estimated_area_range[0]), float(env.estimated_area_range[1])], np.float64))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ smoothing
+def record_smooth_trace(points, actions: np.ndarray, smooth_every: int, iteration: int = 400, max_v: int = 96) -> dict:
+    """Drive step() and, after every `smooth_every`-th accepted element of an episode, call the reference's
+    smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=..., interior=True) (general/mesh.py:790-795 =
+    smooth_fixed_vertices + find_reference_candidates(0); the call general/EBRD.py:393 makes on an unfinished mesh).
+    Recorded per call: the step index it follows, the vertex table before and after, the sweep count (the reference only
+    prints it), the element log and ring at that moment, the rebuilt candidate list.  The step records that follow show
+    that stepping continues from the smoothed state exactly as the reference's does."""
+    import contextlib
+    import io
+    import re
+    env = make_env(points)
+    n0 = len(points)
+    T = len(actions)
+    reset_obs = env.reset()
+
+    def ids_of(vlist):
+        table = {id(v): k for k, v in enumerate(env.boundary.vertices)}
+        return [table[id(v)] for v in vlist]
+
+    out = dict(
+        obs=np.zeros((T, 18), np.float32), obs_none=np.zeros(T, np.uint8), reward=np.zeros(T, np.float64),
+        done=np.zeros(T, np.uint8), complete=np.zeros(T, np.uint8), ring_len=np.zeros(T, np.int32),
+        n_elem=np.zeros(T, np.int32), ref_id=np.full(T, -1, np.int32), valid=np.zeros(T, np.uint8),
+    )
+    calls = []
+    since = 0
+    for t in range(T):
+        nelem_before = len(env.generated_meshes)
+        obs, rew, done, info = env.step(actions[t])
+        out["obs_none"][t] = obs is None
+        if obs is not None:
+            out["obs"][t] = obs
+        out["reward"][t] = rew
+        out["done"][t] = done
+        out["complete"][t] = info["is_complete"]
+        out["ring_len"][t] = len(env.updated_boundary.vertices)
+        out["n_elem"][t] = len(env.generated_meshes)
+        out["ref_id"][t] = ids_of([env.current_point_environment.reference_point])[0]
+        valid = len(env.generated_meshes) > nelem_before
+        out["valid"][t] = valid
+        since += int(valid)
+        if done:
+            env.reset()
+            since = 0
+        elif valid and since >= smooth_every and len(env.boundary.vertices) <= max_v:
+            since = 0
+            before = np.array([(v.x, v.y) for v in env.boundary.vertices], np.float64)
+            quads = np.array([ids_of(m.vertices) for m in env.generated_meshes], np.int32)
+            ring = np.array(ids_of(env.updated_boundary.vertices), np.int32)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                env.smooth_pave(env.boundary.vertices, env.updated_boundary.vertices, iteration=iteration, interior=True)
+            m = re.search(r"Iteration numbers: (\d+), the diff of smoothing is ([-+0-9.e]+)!", buf.getvalue())
+            after = np.array([(v.x, v.y) for v in env.boundary.vertices], np.float64)
+            cv = env.candidate_vertices
+            calls.append(dict(t=t, before=before, after=after, quads=quads, ring=ring, sweeps=int(m.group(1)),
+                              diff=float(m.group(2)), cand_ids=np.array(ids_of([c[0] for c in cv]), np.int32),
+                              cand_keys=np.array([float(c[1]) for c in cv], np.float64)))
+    out.update(domain_xy=np.array(points, np.float64), actions=actions, reset_obs=reset_obs.astype(np.float32),
+               consts=np.array([float(env.original_area), float(env.average_edge_length),
+                                float(env.estimated_area_range[0]), float(env.estimated_area_range[1])], np.float64),
+               n_calls=np.int32(len(calls)), iteration=np.int32(iteration))
+    # ragged per-call arrays, padded to the largest
+    if calls:
+        V = max(len(c["before"]) for c in calls)
+        E = max(len(c["quads"]) for c in calls)
+        R = max(len(c["ring"]) for c in calls)
+        K = max(len(c["cand_ids"]) for c in calls)
+        nC = len(calls)
+        out.update(
+            call_t=np.array([c["t"] for c in calls], np.int32), call_sweeps=np.array([c["sweeps"] for c in calls], np.int32),
+            call_diff=np.array([c["diff"] for c in calls], np.float64),
+            call_nv=np.array([len(c["before"]) for c in calls], np.int32),
+            call_ne=np.array([len(c["quads"]) for c in calls], np.int32),
+            call_nr=np.array([len(c["ring"]) for c in calls], np.int32),
+            call_nc=np.array([len(c["cand_ids"]) for c in calls], np.int32),
+            call_before=np.full((nC, V, 2), np.nan), call_after=np.full((nC, V, 2), np.nan),
+            call_quads=np.full((nC, E, 4), -1, np.int32), call_ring=np.full((nC, R), -1, np.int32),
+            call_cand_ids=np.full((nC, K), -1, np.int32), call_cand_keys=np.full((nC, K), np.nan),
+        )
+        for k, c in enumerate(calls):
+            out["call_before"][k, :len(c["before"])] = c["before"]
+            out["call_after"][k, :len(c["after"])] = c["after"]
+            out["call_quads"][k, :len(c["quads"])] = c["quads"]
+            out["call_ring"][k, :len(c["ring"])] = c["ring"]
+            out["call_cand_ids"][k, :len(c["cand_ids"])] = c["cand_ids"]
+            out["call_cand_keys"][k, :len(c["cand_keys"])] = c["cand_keys"]
+    return out

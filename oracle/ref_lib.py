@@ -42,6 +42,8 @@ def lib():
     L.meshenv_ref_reset_static.argtypes = [C.c_void_p, _f32p, C.c_int]
     L.meshenv_ref_move.restype = C.c_int
     L.meshenv_ref_move.argtypes = [C.c_void_p, _f64p, C.c_double, _f32p, _u8p, _u8p]
+    L.meshenv_ref_smooth_interior.restype = C.c_int
+    L.meshenv_ref_smooth_interior.argtypes = [C.c_void_p, C.c_int, _i32p, _f64p]
     L.meshenv_ref_not_valid_count.restype = C.c_int
     L.meshenv_ref_not_valid_count.argtypes = [C.c_void_p]
     L.meshenv_ref_step.restype = C.c_int
@@ -139,6 +141,13 @@ class RefEnv:
         p = np.ascontiguousarray(point, np.float64).reshape(2)
         code = self.L.meshenv_ref_move(self.h, p, float(type_), self._obs, self._done, self._comp)
         return self._obs.copy(), bool(self._done[0]), bool(self._comp[0]), int(code)
+
+    def smooth_interior(self, iteration=400):
+        """smooth_pave(..., iteration=iteration, interior=True) -> (sweeps, final diff); raises on a log overflow."""
+        sw = np.zeros(1, np.int32); df = np.zeros(1, np.float64)
+        if self.L.meshenv_ref_smooth_interior(self.h, int(iteration), sw, df) != 0:
+            raise RuntimeError("meshenv_ref_smooth_interior: element / vertex log overflow or vertex degree > 16")
+        return int(sw[0]), float(df[0])
 
     def not_valid_count(self):
         return int(self.L.meshenv_ref_not_valid_count(self.h))

@@ -17,12 +17,17 @@ def pytest_configure(config):
 def golden_names():
     """Recorded reference traces (quality_*.npz holds element records, not a trace)."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
-                  if f.endswith(".npz") and not f.startswith(("quality_", "move_")))
+                  if f.endswith(".npz") and not f.startswith(("quality_", "move_", "smooth_")))
 
 
 def move_golden_names():
     """Recorded traces of the reference's move() API (oracle/gen_golden.py --move-only)."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("move_"))
+
+
+def smooth_golden_names():
+    """Recorded step() traces with smooth_pave(interior=True) calls in between (oracle/gen_golden.py --smooth-only)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("smooth_"))
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,54 @@
+"""CPU: the oracle's smooth_pave(interior=True) against records of the reference's own (tests/golden/smooth_*.npz,
+written by oracle/gen_golden.py --smooth-only from general/mesh.py:790-795,1258-1288): vertex table after every call
+BIT-exact, sweep count, rebuilt candidate list, and every step() after it (the smoothed state is the one stepped on)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, smooth_golden_names
+from smooth_replay import replay
+
+
+class OracleImpl:
+    def __init__(self, tr):
+        from oracle.ref_lib import RefEnv
+        c = tr["consts"]
+        self.env = RefEnv(tr["domain_xy"], c[0], c[2], c[3], cap_new=512)
+
+    def reset(self):
+        return self.env.reset()[0]
+
+    def step(self, a):
+        o, r, d, c, _none = self.env.step(a)
+        return o, r, d, c
+
+    def smooth(self, iteration):
+        return self.env.smooth_interior(iteration)[0]
+
+    def vertices(self):
+        return self.env.elements()[1]
+
+    def elements(self):
+        return self.env.elements()[0]
+
+    def ring_ids(self):
+        return self.env.ring()[0]
+
+    def candidates(self):
+        return self.env.candidates()
+
+
+@pytest.mark.parametrize("name", smooth_golden_names())
+def test_oracle_smooth_interior_matches_reference_records(name):
+    tr = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    moved = replay(tr, OracleImpl(tr))
+    assert int(tr["n_calls"]) >= 8 and moved > 0
+
+
+def test_smooth_fixtures_cover_both_stop_rules():
+    trs = [dict(np.load(os.path.join(GOLDEN_DIR, n + ".npz"))) for n in smooth_golden_names()]
+    assert any((t["call_sweeps"] == int(t["iteration"])).any() for t in trs)       # stopped by the iteration cap
+    assert any(((t["call_sweeps"] > 1) & (t["call_sweeps"] < int(t["iteration"]))).any() for t in trs)   # by the 0.001 rule
+    assert any((t["call_sweeps"] >= 40).any() for t in trs)
+    assert any((t["call_nv"] - t["domain_xy"].shape[0] >= 30).any() for t in trs)   # dozens of generated vertices
