@@ -206,6 +206,22 @@ enum {
 int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, float *obs_dev, uint8_t *done_dev,
                  uint8_t *complete_dev, uint8_t *code_dev);
 
+/* MeshGeneration.smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=..., interior=True),
+ * general/mesh.py:790-795 (the post-processing call of general/EBRD.py:393), on the RUNNING episode of every env with
+ * mask_dev[e] != 0 (mask_dev NULL: all): smooth_fixed_vertices (general/mesh.py:1258-1288) -- Gauss-Seidel relaxation of
+ * the generated vertices that are off the front, in boundary.vertices order, until the moved vertices' coordinate sum
+ * changes by <= 0.001 or `iteration` sweeps -- then find_reference_candidates(0) (general/mesh.py:233-261) on the front.
+ * The Vertex.segments graph the reference walks is rebuilt from the element log, so the handle needs log_capacity > 0.
+ * The vertex log (meshenv_get_elements, meshenv_element_quality) holds the moved coordinates afterwards; the front, the
+ * reference vertex and the observation are unchanged (as in the reference), the candidate list is the rebuilt one.
+ *   sweeps_dev [n_envs] int32, nullable: sweeps made; MESHENV_SMOOTH_SKIPPED for masked-out envs,
+ *              MESHENV_SMOOTH_LOG_OVERFLOW (status bit MESHENV_ST_LOG_OVERFLOW: graph incomplete) and
+ *              MESHENV_SMOOTH_DEGREE (a vertex with more than 16 neighbours) leave the env untouched
+ *   diff_dev   [n_envs] float64, nullable: the last |sum - previous sum| (what the reference prints)
+ * interior = 0 (smooth_current_boundary_3 on the front itself, general/mesh.py:939-1028) is not built: MESHENV_E_ARG. */
+enum { MESHENV_SMOOTH_SKIPPED = -1, MESHENV_SMOOTH_LOG_OVERFLOW = -2, MESHENV_SMOOTH_DEGREE = -3 };
+int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int interior, int32_t *sweeps_dev, double *diff_dev);
+
 /* Host-side readout of one env's not_valid_points (synchronises the stream): xy_host[2*cap_points], *count = length. */
 int meshenv_get_not_valid(MeshEnv *h, int env, double *xy_host, int cap_points, int32_t *count);
 

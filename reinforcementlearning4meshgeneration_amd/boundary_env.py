@@ -93,6 +93,16 @@ class BoudaryEnv:  # the reference's spelling
         self.current_state = obs_np
         return obs_np, 0, bool(done.cpu()[0]), {"is_complete": bool(comp.cpu()[0])}
 
+    def smooth_pave(self, vertices=None, current_boundary_vertices=None, lr_1=None, lr_2=None, iteration=400,
+                    interior=False):
+        """MeshGeneration.smooth_pave, general/mesh.py:790-795.  The two vertex lists of the reference's signature are
+        implied here (boundary.vertices and the current front of this env) and ignored; lr_1 / lr_2 are unused by the
+        reference as well.  interior=True (the call general/EBRD.py:393 makes): the generated vertices off the front are
+        relaxed and the candidate list is rebuilt; returns the number of sweeps (the reference prints it).
+        interior=False would first run smooth_current_boundary_3 on the front: not built, NotImplementedError."""
+        sweeps, _ = self._vec.smooth_pave(iteration=iteration, interior=interior)
+        return int(sweeps.cpu()[0])
+
     @property
     def not_valid_points(self):
         """[k, 2] coordinates of the reference vertices rejected since the last valid move (rl/boundary_env.py:47)."""

@@ -18,6 +18,7 @@
 #include "meshenv_domgen.h"
 #include "meshenv_kernels.h"
 #include "meshenv_quality.h"
+#include "meshenv_smooth.h"
 
 using namespace meshenv;
 
@@ -44,6 +45,10 @@ struct MeshEnv {
     int timing = 0;              // 0 = off, k = bracket every other group of k consecutive launches
     long long launch_count = 0;
     std::vector<hipEvent_t> ev;  // 2 * MESHENV_TIMING_POOL events, created on first use
+    int32_t *smooth_sweeps = nullptr;  // [E], allocated by the first meshenv_smooth: what the smoother did per env
+    Reselect *pend = nullptr;          // [E] selection parked by the candidate rebuild (csrc/meshenv_smooth.h)
+    float *pend_obs = nullptr;         // [E][18]
+    bool reselect_pending = false;     // a rebuild ran since the last step kernel
     // move() API state, allocated by the first meshenv_move: not_valid_points per env
     double2 *nv_xy = nullptr;    // [E][cap]
     int32_t *nv_count = nullptr; // [E]
@@ -528,6 +533,46 @@ int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, f
     hipLaunchKernelGGL(k_move, dim3(h->n_envs), dim3(64), move_lds_bytes(h->cap), h->stream, h->S, h->cap, points_dev, type_dev,
                        obs_dev, done_dev, complete_dev, code_dev, h->nv_xy, h->nv_count);
     HIP_TRY(h, hipGetLastError());
+    if (h->reselect_pending) {  // move() ends with its own selection from the list, accepted or not: nothing stays parked
+        HIP_TRY(h, hipMemsetAsync(h->pend, 0xff, sizeof(Reselect) * (size_t)h->n_envs, h->stream));
+        h->reselect_pending = false;
+    }
+    return MESHENV_OK;
+}
+
+int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int interior, int32_t *sweeps_dev, double *diff_dev)
+{
+    if (!h) return MESHENV_E_ARG;
+    if (!interior)
+        return fail_arg(h, "meshenv_smooth: interior = 0 (smooth_current_boundary_3 on the front, general/mesh.py:939-1028) is not built");
+    if (iteration < 0) return fail_arg(h, "meshenv_smooth: iteration must be >= 0");
+    const int log_cap = h->S.prm.log_cap;
+    if (log_cap <= 0) {
+        h->err = "meshenv_smooth: handle was created with log_capacity = 0 (the mesh graph is rebuilt from the element log)";
+        return MESHENV_E_STATE;
+    }
+    const size_t lds = smooth_lds_bytes(h->cap, log_cap);
+    if (lds > 160 * 1024 || h->cap + log_cap > 65535)
+        return fail_arg(h, "meshenv_smooth: ring stride + log_capacity too large for the smoother's LDS (16 B per vertex + 34 B per logged vertex)");
+    MESHENV_ON_DEVICE(h);
+    if (!h->smooth_sweeps) {
+        const int rc = dev_alloc(h, &h->smooth_sweeps, (size_t)h->n_envs);
+        if (rc != MESHENV_OK) return rc;
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_smooth_interior, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int rc2 = dev_alloc(h, &h->pend, (size_t)h->n_envs);
+        if (rc2 != MESHENV_OK) return rc2;
+        rc2 = dev_alloc(h, &h->pend_obs, (size_t)h->n_envs * kObsDim);
+        if (rc2 != MESHENV_OK) return rc2;
+        HIP_TRY(h, hipMemsetAsync(h->pend, 0xff, sizeof(Reselect) * (size_t)h->n_envs, h->stream));   // n_elem = -1: nothing parked
+    }
+    int32_t *sw = sweeps_dev ? sweeps_dev : h->smooth_sweeps;
+    hipLaunchKernelGGL(k_smooth_interior, dim3(h->n_envs), dim3(64), lds, h->stream, h->S, h->cap, mask_dev, iteration, sw, diff_dev);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(k_rebuild_candidates, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend,
+                       h->pend_obs);
+    HIP_TRY(h, hipGetLastError());
+    h->reselect_pending = true;
     return MESHENV_OK;
 }
 
@@ -558,6 +603,11 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
     if (!h) return MESHENV_E_ARG;
     if (!actions_dev || !obs_dev || !reward_dev || !done_dev || !complete_dev) return fail_arg(h, "meshenv_step: null device pointer");
     if (n_steps <= 0) return fail_arg(h, "meshenv_rollout: n_steps must be positive");
+    if (n_steps > 1 && h->reselect_pending) {
+        h->err = "meshenv_rollout: the first step after meshenv_smooth must be a meshenv_step (it commits the re-selection "
+                 "the candidate rebuild parked, include/meshenv.h)";
+        return MESHENV_E_STATE;
+    }
     MESHENV_ON_DEVICE(h);
     const size_t slot = (size_t)(h->ev_count % MESHENV_TIMING_POOL);
     const long long pos = h->timing > 0 ? (h->launch_count++ % (2LL * h->timing)) : -1;
@@ -597,6 +647,11 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
 #undef MESHENV_LAUNCH_STEP
     }
     HIP_TRY(h, hipGetLastError());
+    if (h->reselect_pending) {  // the step after a candidate rebuild: envs whose action was rejected take the parked selection
+        hipLaunchKernelGGL(k_apply_reselect, dim3(h->n_envs), dim3(64), 0, h->stream, h->S, h->pend, h->pend_obs, obs_dev);
+        HIP_TRY(h, hipGetLastError());
+        h->reselect_pending = false;
+    }
     h->steps_done += (uint64_t)n_steps;
     if (pos >= 0 && pos == h->timing - 1) {
         HIP_TRY(h, hipEventRecord(h->ev[2 * slot + 1], h->stream));

@@ -1,0 +1,254 @@
+// meshenv_smooth.h -- post-processing smoothing of the generated mesh:
+// MeshGeneration.smooth_pave(vertices, current_boundary_vertices, iteration=..., interior=True), general/mesh.py:790-795
+//   = smooth_fixed_vertices (M:1258-1288) over the generated vertices that are off the front
+//   + find_reference_candidates(target_angle=0) (M:233-261).
+// (interior=False additionally runs smooth_current_boundary_3, M:939-1028, on the front itself: not built.)
+//
+// The reference relaxes on the Vertex.segments graph.  The hot path does not keep that graph; everything the smoother
+// reads from it is recoverable from the element log: only generated vertices move (`vertex in self.original_vertices`
+// skips the domain's), a generated vertex receives segments only from Mesh.connect_vertices (C:832-837) of the elements
+// that contain it -- for i = 0..3 the pair (vertices[i], vertices[i-1]), unless the two are connected already -- and
+// get_connected_vertices (C:115-124) lists the other end of every segment in list order.  So the neighbour list of a
+// generated vertex = the partners of those pairs over the elements in log order, first occurrence only; for a vertex at
+// position p of a quad the two pairs come in the order (p, p-1), (p+1, p) for p < 3 and (0, 3), (3, 2) for p = 3.
+//
+// The relaxation is Gauss-Seidel in boundary.vertices order (every vertex sees the new position of its predecessors),
+// each coordinate accumulated term by term as x += (neighbour.x + vertex.x); the sweeps stop when the running sum of the
+// moved vertices' x + y differs from the previous sweep's by <= 0.001, or after `iteration` sweeps.  Bit parity with that
+// needs the same order of the same additions, so a sweep is serial per env by definition of the algorithm; what runs in
+// parallel is envs (one wavefront each) and, inside a wavefront, the neighbour gather of the vertex being moved (one lane
+// per neighbour: index and coordinates from LDS in two reads, the term neighbour + vertex in parallel, then the ordered
+// sum over <= 16 lanes through v_readlane).  The graph (neighbour indices, 16 x uint16 per generated vertex) is built in
+// LDS by one lane per generated vertex scanning the element log, and the coordinates of the domain ring and of the
+// generated vertices sit in one LDS array, so that a sweep touches no HBM: HBM traffic is the logs once in, the moved
+// coordinates once out.
+#pragma once
+
+#include "meshenv_kernels.h"
+
+namespace meshenv {
+
+constexpr int kSmoothMaxDeg = 16;   // neighbours per generated vertex (a quad-mesh vertex has 3-6; more sets code -3)
+
+enum { kSmoothSkipped = -1, kSmoothLogOverflow = -2, kSmoothDegree = -3 };
+
+// LDS: coord[n0_max + log_cap] double2 | adj[log_cap][16] uint16 | deg[log_cap] uint8 | front[log_cap] uint8
+__host__ __device__ __forceinline__ size_t smooth_lds_bytes(int ring_cap, int log_cap)
+{
+    return (size_t)(ring_cap + log_cap) * sizeof(double2) + (size_t)log_cap * (kSmoothMaxDeg * 2 + 2) + 64;
+}
+
+// One wavefront per env.  sweeps_out[env]: sweeps made (>= 1 when a vertex could move; 1 with nothing to move, as the
+// reference's loop), or kSmoothSkipped (masked out), kSmoothLogOverflow (graph incomplete: nothing changed),
+// kSmoothDegree.  diff_out[env]: the last |sum - previous sum| (the number the reference prints).
+__global__ void __launch_bounds__(64)
+k_smooth_interior(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int iteration, int32_t *__restrict__ sweeps_out,
+                  double *__restrict__ diff_out)
+{
+    extern __shared__ double2 smem[];
+    const int env = blockIdx.x, lane = lane_id();
+    if (mask && mask[env] == 0) {
+        if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothSkipped;
+        return;
+    }
+    const int log_cap = S.prm.log_cap;
+    const EnvScalars sc = S.scal[env];
+    const DevCold cold = load_cold(S);
+    const int n = uniform_i32(sc.n), n_elem = uniform_i32(sc.n_elem), n_new = uniform_i32(sc.n_new);
+    const int status = uniform_i32(sc.status);
+    if ((status & kStLogOverflow) || n_elem > log_cap || n_new > log_cap) {
+        if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothLogOverflow;
+        return;
+    }
+    const DomConst dc = S.dom[uniform_i32(sc.dom)];
+    const int doff = uniform_i32(dc.off), n0 = uniform_i32(dc.n0);
+    const size_t lbase = ((size_t)env * 2 + ((status >> 4) & 1)) * log_cap;
+    const int4 *quads = reinterpret_cast<const int4 *>(cold.log_quads + lbase * 4);
+    double2 *vnew = cold.log_vxy + lbase;
+
+    double2 *coord = smem;                                              // [0, n0): domain ring, [n0, n0 + n_new): generated
+    unsigned short *adj = (unsigned short *)(coord + ring_cap + log_cap);
+    unsigned char *deg = (unsigned char *)(adj + (size_t)log_cap * kSmoothMaxDeg);
+    unsigned char *front = deg + log_cap;
+
+    for (int i = lane; i < n0; i += 64) coord[i] = cold.dom_xy[doff + i];
+    for (int k = lane; k < n_new; k += 64) {
+        coord[n0 + k] = vnew[k];
+        front[k] = 0;
+    }
+    wave_sync();
+    // `[v for v in vertices if v not in current_boundary_vertices]`, M:794
+    const int32_t *rid = S.ring_id + (size_t)env * S.cap;
+    for (int i = lane; i < n; i += 64) {
+        const int g = rid[i];
+        if (g & kNewBit) front[g & ~kNewBit] = 1;
+    }
+    // the neighbour lists: one lane per generated vertex, the element log read by all lanes at the same address
+    bool too_many = false;
+    for (int k0 = 0; k0 < n_new; k0 += 64) {
+        const int k = k0 + lane;
+        const int me = kNewBit | k;
+        unsigned short mine[kSmoothMaxDeg] = {};
+        int d = 0;
+        for (int e = 0; e < n_elem; e++) {
+            const int4 q = quads[e];
+            const int p = q.x == me ? 0 : (q.y == me ? 1 : (q.z == me ? 2 : (q.w == me ? 3 : -1)));
+            if (p < 0 || k >= n_new) continue;
+            // pairs (i, i-1) for i = 0..3 that contain position p, in the order of i
+            const int first = p == 0 ? q.w : (p == 1 ? q.x : (p == 2 ? q.y : q.x));
+            const int second = p == 0 ? q.y : (p == 1 ? q.z : (p == 2 ? q.w : q.z));
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int g = s == 0 ? first : second;
+                const unsigned short u = (unsigned short)((g & kNewBit) ? n0 + (g & ~kNewBit) : g);
+                bool have = false;
+#pragma unroll
+                for (int j = 0; j < kSmoothMaxDeg; j++) have = have || (j < d && mine[j] == u);
+                if (!have) {
+                    if (d < kSmoothMaxDeg) {
+#pragma unroll
+                        for (int j = 0; j < kSmoothMaxDeg; j++)
+                            if (j == d) mine[j] = u;
+                        d += 1;
+                    } else {
+                        too_many = true;
+                    }
+                }
+            }
+        }
+        if (k < n_new) {
+#pragma unroll
+            for (int j = 0; j < kSmoothMaxDeg; j++) adj[(size_t)k * kSmoothMaxDeg + j] = mine[j];
+            deg[k] = (unsigned char)d;
+        }
+    }
+    if (__ballot(too_many) != 0ULL) {
+        if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothDegree;
+        return;
+    }
+    wave_sync();
+    // smooth_fixed_vertices, M:1258-1288
+    double sum_coordinates = 0.0, diffs = 100.0;
+    int it = 0;
+    while (diffs > 0.001 && it < iteration) {
+        it += 1;
+        double new_sum = 0.0;
+        for (int k = 0; k < n_new; k++) {
+            const int d = uniform_i32((int)deg[k]);
+            if (uniform_i32((int)front[k]) != 0 || d == 0) continue;
+            const double2 v = coord[n0 + k];
+            double tx = 0.0, ty = 0.0;
+            if (lane < d) {
+                const double2 c = coord[adj[(size_t)k * kSmoothMaxDeg + lane]];
+                tx = c.x + v.x;
+                ty = c.y + v.y;
+            }
+            double x = 0.0 + lane_f64(tx, 0), y = 0.0 + lane_f64(ty, 0);   // the reference starts from an int 0
+            for (int j = 1; j < d; j++) {
+                x += lane_f64(tx, j);
+                y += lane_f64(ty, j);
+            }
+            const double nx = x / (double)(2 * d), ny = y / (double)(2 * d);
+            if (lane == 0) coord[n0 + k] = make_double2(nx, ny);
+            new_sum += nx + ny;
+            wave_sync();
+        }
+        diffs = fabs(new_sum - sum_coordinates);
+        sum_coordinates = new_sum;
+    }
+    for (int k = lane; k < n_new; k += 64)
+        if (front[k] == 0 && deg[k] != 0) vnew[k] = coord[n0 + k];
+    if (lane == 0) {
+        if (sweeps_out) sweeps_out[env] = it;
+        if (diff_out) diff_out[env] = diffs;
+    }
+}
+
+// What step()'s closing find_next_state (B:250) will select from the rebuilt list, computed at rebuild time.
+//
+// The reference re-selects the reference vertex from the candidate list at the end of EVERY step(), accepted or not; the
+// step kernels do so only after an accepted element, because between two accepted elements nothing the selection reads
+// can change -- except through this rebuild (a list ordered by insertion becomes a list ordered by ring position, so its
+// head may move).  The reference's next step() still acts on the OLD reference vertex and returns the observation of the
+// NEW one; if that action is rejected the ring is the one at hand, so the new selection is known now.  It is parked here
+// and committed by k_apply_reselect right after the next step kernel for the envs whose step extracted nothing (an
+// extraction re-selects by itself).
+struct alignas(32) Reselect {
+    int32_t n_elem;      // len(generated_meshes) at the rebuild (-1: nothing pending); the next step rejected <=> unchanged
+    int32_t ref;         // ring slot of the new reference vertex (-1: the reference returns None)
+    double bl, ct, st;   // base length and action frame of the new point environment
+};
+
+// find_reference_candidates(target_angle=0), M:233-261, on the CURRENT front of every selected env: the candidate list is
+// rebuilt from scratch (keys from the ring as it is, ties in ring order: stamp = -index, the insertion counter restarts).
+// The point environment -- reference vertex, base length, observation -- is left alone, as in the reference, whose next
+// step() still acts on the reference vertex chosen before the call; the selection that step will end with is parked in
+// pend / pend_obs (above).
+__global__ void __launch_bounds__(64)
+k_rebuild_candidates(DevState S, int cap, const uint8_t *__restrict__ mask, const int32_t *__restrict__ sweeps,
+                     Reselect *__restrict__ pend, float *__restrict__ pend_obs)
+{
+    extern __shared__ double2 smem[];
+    const int env = blockIdx.x;
+    if (mask && mask[env] == 0) return;
+    if (sweeps && sweeps[env] < 0) return;   // the smoother refused this env: nothing changed
+    Ctx c;
+    carve_lds(c, smem, cap);
+    load_env(c, S, env);
+    for (int i = c.lane; i < c.n; i += 64) {
+        double cc, dd, k = 0.0;
+        key_angle_terms(c, i, 0, cc, dd);
+        const double a0 = cw_finish(atan2_nc(cc, dd));
+        key_angle_terms(c, i, 1, cc, dd);
+        const double a1 = cw_finish(atan2_nc(cc, dd));
+        const bool ok = key_from_angles(S.prm, a0, a1, k);
+        c.key[i] = k;
+        c.stamp[i] = ok ? -i : kNotCand;
+    }
+    c.counter = 0;
+    // the selection of the next step's find_next_state, on a scratch copy of the point environment
+    const int ref0 = c.ref, status0 = c.status;
+    const double bl0 = c.bl, ct0 = c.ct, st0 = c.st;
+    const float obs0 = c.obs;
+    BqArgs bq;
+    bq.skip = false;
+    bq.mode = 0; bq.a = 0; bq.b = 0; bq.ang0 = 0; bq.ang1 = 0; bq.q_ang0 = 0; bq.q_ang2 = 0; bq.half01 = 0; bq.half23 = 0;
+    find_next_state(c, S, bq);
+    if (c.lane < kObsDim) pend_obs[(size_t)env * kObsDim + c.lane] = c.obs;
+    if (c.lane == 0) {
+        Reselect r;
+        r.n_elem = c.n_elem; r.ref = c.ref; r.bl = c.bl; r.ct = c.ct; r.st = c.st;
+        pend[env] = r;
+    }
+    c.ref = ref0; c.status = status0; c.bl = bl0; c.ct = ct0; c.st = st0; c.obs = obs0;
+    c.ring_dirty = true;
+    store_env(c, S);
+}
+
+// Runs right after the step kernel while a rebuild is pending: an env whose step extracted nothing (n_elem unchanged)
+// takes the parked selection -- record, cached observation and the step's observation outputs; the others (extraction:
+// re-selected by the step itself; reset: a fresh episode) only drop it.
+__global__ void __launch_bounds__(64)
+k_apply_reselect(DevState S, Reselect *__restrict__ pend, const float *__restrict__ pend_obs, float *__restrict__ obs_out)
+{
+    const int env = blockIdx.x, lane = lane_id();
+    const Reselect r = pend[env];
+    if (uniform_i32(r.n_elem) < 0) return;
+    if (lane == 0) pend[env].n_elem = -1;
+    EnvScalars *sc = S.scal + env;
+    if (uniform_i32(sc->n_elem) != uniform_i32(r.n_elem)) return;
+    if (lane < kObsDim) {
+        const float o = pend_obs[(size_t)env * kObsDim + lane];
+        S.obs_cache[(size_t)env * kObsDim + lane] = o;
+        if (obs_out) obs_out[(size_t)env * kObsDim + lane] = o;
+        if (S.msg) S.msg[(size_t)env * 21 + lane] = o;
+    }
+    if (lane == 0) {
+        sc->ref = r.ref;
+        sc->bl = r.bl; sc->ct = r.ct; sc->st = r.st;
+        // the memo of rejected rule -1 / +1 quads is tied to the reference vertex
+        sc->status = (sc->status & ~(kStRm1Bad | kStRp1Bad | kStNoReference)) | (r.ref < 0 ? kStNoReference : 0);
+    }
+}
+
+}  // namespace meshenv

@@ -271,6 +271,31 @@ class MeshVecEnv:
         self._check(rc, "meshenv_move")
         return self.obs, self.done, self.complete, self.move_code
 
+    def smooth_pave(self, mask=None, iteration: int = 400, interior: bool = True):
+        """MeshGeneration.smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=iteration, interior=True)
+        (general/mesh.py:790-795) on the running episode of every env (mask: uint8/bool CUDA [n], None = all): the
+        generated vertices off the front are relaxed (smooth_fixed_vertices) and the candidate list is rebuilt; the vertex
+        log (`generated_meshes`, the quality report) then holds the moved coordinates.  Needs log_capacity > 0.
+        Returns (sweeps int32 [n], diff float64 [n]); sweeps < 0: _capi.SMOOTH_* (env untouched).  interior=False (the
+        front smoother smooth_current_boundary_3) is not built and raises NotImplementedError."""
+        if not interior:
+            raise NotImplementedError("smooth_pave(interior=False): smooth_current_boundary_3 (general/mesh.py:939-1028) is not built")
+        t = self._torch
+        if not hasattr(self, "smooth_sweeps"):
+            self.smooth_sweeps = t.zeros(self.num_envs, dtype=t.int32, device=self.device)
+            self.smooth_diff = t.zeros(self.num_envs, dtype=t.float64, device=self.device)
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=t.uint8).contiguous()
+            if tuple(mask.shape) != (self.num_envs,):
+                raise ValueError(f"mask must have shape ({self.num_envs},)")
+            mptr = mask.data_ptr()
+        self._bind_stream()
+        rc = self._L.meshenv_smooth(self._handle, mptr, int(iteration), 1, self.smooth_sweeps.data_ptr(),
+                                    self.smooth_diff.data_ptr())
+        self._check(rc, "meshenv_smooth")
+        return self.smooth_sweeps, self.smooth_diff
+
     def get_not_valid(self, env: int) -> np.ndarray:
         """not_valid_points of one env (rl/boundary_env.py:47): [k, 2] coordinates of the reference vertices whose
         moves were rejected since the last valid move / reset."""

@@ -12,7 +12,7 @@ oracle (tests/test_oracle_smooth.py) or the HIP path (tests/test_gpu_smooth.py):
 import numpy as np
 
 
-def replay(tr, impl, obs_tol=0.0, exact_vertices=True):
+def replay(tr, impl, obs_tol=0.0, exact_vertices=True, key_tol=0.0):
     T = len(tr["actions"])
     calls = {int(t): k for k, t in enumerate(tr["call_t"])} if int(tr["n_calls"]) else {}
     iteration = int(tr["iteration"])
@@ -44,5 +44,5 @@ def replay(tr, impl, obs_tol=0.0, exact_vertices=True):
             moved_total += int(np.any(want != tr["call_before"][k, :nv], axis=1).sum())
             ids, keys = impl.candidates()
             assert np.array_equal(ids, tr["call_cand_ids"][k, :nc]), t
-            assert np.array_equal(keys, tr["call_cand_keys"][k, :nc]), t
+            assert np.abs(keys - tr["call_cand_keys"][k, :nc]).max(initial=0.0) <= key_tol, t
     return moved_total

@@ -1,0 +1,54 @@
+"""Dev tool: time meshenv_smooth (smooth_pave(interior=True): k_smooth_interior + k_rebuild_candidates) on a batch of
+partly meshed envs, against the oracle's smooth_interior on a shadowed subset (same actions, so same states).
+
+usage: python tools/bench_smooth.py [n_envs] [steps] [workload: boundary0 | d1]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from reinforcementlearning4meshgeneration_amd import MeshVecEnv, boundary
+from oracle.ref_lib import RefBatch, RefEnv
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+wl = sys.argv[3] if len(sys.argv) > 3 else "boundary0"
+if wl == "d1":
+    dom = [tuple(p) for p in np.load(os.path.join(ROOT, "tests", "golden", "boundary16_biased_s2.npz"))["domain_xy"]]
+else:
+    dom = boundary(0)
+cap = 128
+shadow = 256
+warm = MeshVecEnv([dom], n_envs=64, auto_reset=False, log_capacity=cap)   # code load, first-call allocations
+warm.reset(); warm.smooth_pave(); warm.close()
+env = MeshVecEnv([dom], n_envs=n, auto_reset=False, log_capacity=cap)
+refs = [RefEnv.from_points(dom, cap_new=cap) for _ in range(shadow)]
+batch = RefBatch(refs)
+env.reset(); batch.reset()
+rng = np.random.default_rng(3)
+for t in range(T):
+    a = rng.uniform([-1, 0.2, 0.3], [1, 1.0, 1.2], size=(n, 3)).astype(np.float32)
+    o, r, d, c = env.step(torch.from_numpy(a).cuda())
+    batch.step(a[:shadow], auto_reset=False, threads=16)
+    if d.any():   # finished meshes stay as they are: mask them out of further steps by resetting nothing (auto_reset off)
+        pass
+st = [env.get_state(k) for k in range(0, n, max(1, n // 64))]
+print(f"{n} envs, {T} steps: elements/env {np.mean([s['n_elem'] for s in st]):.1f}, generated vertices/env "
+      f"{np.mean([s['n_vert'] - s['n0'] for s in st]):.1f}, front {np.mean([s['n'] for s in st]):.1f}")
+env.smooth_pave(iteration=0)   # allocations of this handle, no sweep
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+sweeps, diff = env.smooth_pave(iteration=400)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+sw = sweeps.cpu().numpy()
+print(f"device: {ms:.3f} ms for {n} envs ({ms * 1e3 / n:.3f} us/env), sweeps mean {sw.mean():.1f} max {sw.max()}, "
+      f"total sweeps {int(sw.sum())}")
+t0 = time.perf_counter()
+ref_sw = np.array([e.smooth_interior(400)[0] for e in refs])
+dt = time.perf_counter() - t0
+assert np.array_equal(ref_sw, sw[:shadow]), "device and oracle sweep counts differ"
+for k in range(0, shadow, 16):
+    assert np.array_equal(env.get_elements(k)[1], refs[k].elements()[1])
+print(f"oracle (1 thread): {dt / shadow * 1e6:.1f} us/env -> {dt / shadow * n * 1e3:.1f} ms for {n} envs; device/oracle speed "
+      f"{dt / shadow * n * 1e3 / ms:.0f}x; shadowed vertex tables bit-identical")
