@@ -214,6 +214,34 @@ def main_smooth():
               f"{tr['call_sweeps'].tolist() if tr['n_calls'] else []}")
 
 
+# finished meshes: (fixture name, domain, stream kind, seed, T, iteration cap)
+FINAL_SMOOTH_TRACES = [
+    ("smoothfinal_boundary0_s7", "boundary0", "uniform", 7, 3000, 400),
+    ("smoothfinal_boundary0_s21", "boundary0", "uniform", 21, 3000, 400),
+    ("smoothfinal_boundary0_s33", "boundary0", "biased", 33, 2500, 12),    # the iteration cap ends the sweeps
+    ("smoothfinal_star_s6", "star", "biased", 6, 1200, 400),
+    ("smoothfinal_ring13_s4", "RING13", "biased", 4, 1500, 400),           # odd ring: episodes end on a front of 5
+    ("smoothfinal_ring21_s9", "RING21", "biased", 9, 2500, 400),
+]
+
+
+def odd_ring(n, radius):
+    """clockwise n-gon with a mild radial wobble, coordinates rounded to 2 decimals (data, not reference code)"""
+    return [(round(radius * (1 + 0.08 * math.sin(3 * k)) * math.cos(-2 * math.pi * k / n), 2),
+             round(radius * (1 + 0.08 * math.sin(3 * k)) * math.sin(-2 * math.pi * k / n), 2)) for k in range(n)]
+
+
+def main_final_smooth():
+    for name, dom, kind, seed, T, iteration in FINAL_SMOOTH_TRACES:
+        acts = (H.uniform_actions if kind == "uniform" else H.biased_actions)(seed, T)
+        pts = odd_ring(int(dom[4:]), 0.9 * int(dom[4:]) / 6) if dom.startswith("RING") else H.domain_points(dom)
+        tr = H.record_final_smooth_trace(pts, acts, iteration=iteration, max_calls=24)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **tr)
+        print(f"{name}: {T} steps, {int(tr['n_calls'])} smooth() calls, sweeps "
+              f"{tr['call_sweeps'].tolist() if tr['n_calls'] else []}, front {tr['call_nr'].tolist() if tr['n_calls'] else []}, "
+              f"branch visits {tr['call_branch'].sum(axis=0).tolist() if tr['n_calls'] else []}")
+
+
 def main_move():
     for name, dom, seed, T, reset_on_done in MOVE_TRACES:
         pts = H.domain_points(dom) if isinstance(dom, str) else dom
@@ -228,6 +256,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if "--smooth-only" in sys.argv:
         main_smooth()
+        main_final_smooth()
         return
     if "--quality-only" in sys.argv:
         quality_fixture()
@@ -245,6 +274,7 @@ def main():
     save("boundary0_targeted", H.record_trace(pts, acts))
     main_move()
     main_smooth()
+    main_final_smooth()
 
 
 if __name__ == "__main__":

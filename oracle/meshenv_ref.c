@@ -967,6 +967,185 @@ int meshenv_ref_smooth_interior(RefEnv *e, int iteration, int32_t *sweeps_out, d
     return 0;
 }
 
+/* ------------------------------------------------- smoothing of a finished mesh: MeshGeneration.smooth(vertices)
+ *
+ * general/mesh.py:1290-1392, the call general/EBRD.py:391 makes once the front is down to <= 5 vertices
+ * (env.smooth(env.boundary.vertices), lr_1 = lr_2 = 0.999).  Every generated vertex, in boundary.vertices order, by the
+ * number of elements that contain it (find_related_meshes, M:556-564):
+ *   1 element : two neighbours -> the 4th-vertex estimate from their common neighbour (M:1307-1326); else a 0.999 pull
+ *   2 elements: one interior + two front neighbours -> mean of two 4th-vertex estimates (M:1338-1361); else the pull
+ *   otherwise : the Laplacian step of smooth_fixed_vertices
+ * and the stop rule sums x + y over ALL of `vertices` (domain ring included), M:1384-1387.  Needs the Vertex.segments
+ * lists of every vertex: the domain ring's own segments first (general/mesh.py:1926-1930: for i: Segment(v[i-1], v[i])
+ * appended to v[i-1] and v[i]), then Mesh.connect_vertices of every element (C:832-837).
+ * Returns 0; -1 log overflow / degree overflow; -2 where the reference would raise IndexError (M:1311 on an empty list). */
+typedef struct {
+    int32_t *adj, *deg;
+} Graph;
+
+static int graph_has(const Graph *g, int v, int w)
+{
+    for (int j = 0; j < g->deg[v]; j++)
+        if (g->adj[v * MESHENV_REF_MAX_DEG + j] == w) return 1;
+    return 0;
+}
+
+static int graph_add(Graph *g, int v, int w)
+{
+    if (g->deg[v] >= MESHENV_REF_MAX_DEG) return -1;
+    g->adj[v * MESHENV_REF_MAX_DEG + g->deg[v]++] = w;
+    return 0;
+}
+
+/* Mesh.estimate_4th_vertex, C:980-990 -> Segment.get_ray_segment / build_ray, C:588-610 */
+static P2 estimate_4th_vertex(P2 origin, P2 left, P2 right, double factor, int has_suggest, double suggest_dist)
+{
+    double distance = (dist(origin, left) + dist(origin, right)) * factor;
+    if (has_suggest) {
+        double lim = 0.6 * suggest_dist;
+        if (lim < distance) distance = lim; /* min(distance, 0.6 * suggest_dist) */
+    }
+    P2 r1 = {(origin.x + origin.x) / 2, (origin.y + origin.y) / 2};
+    P2 r2 = {(left.x + right.x) / 2, (left.y + right.y) / 2};
+    double theta = atan2(r2.y - r1.y, r2.x - r1.x);
+    P2 out = {r1.x + distance * cos(theta), r1.y + distance * sin(theta)};
+    return out;
+}
+
+/* Boundary2D.compute_dist(candidates, point)[0][0], C:369-376: the nearest candidate (stable sort: first among equals) */
+static int nearest_of(const RefEnv *e, const int *cand, int n_cand, int point)
+{
+    int best = -1;
+    double bd = 0.0;
+    for (int j = 0; j < n_cand; j++) {
+        if (cand[j] == point) continue;
+        double d = dist(e->vtab[point], e->vtab[cand[j]]);
+        if (best < 0 || d < bd) { best = cand[j]; bd = d; }
+    }
+    return best;
+}
+
+/* [v for v in a.get_connected_vertices() if v in b.get_connected_vertices()], C:162-165, minus `skip` */
+static int common_vertices(const Graph *g, int a, int b, int skip, int *out)
+{
+    int m = 0;
+    for (int j = 0; j < g->deg[a]; j++) {
+        int v = g->adj[a * MESHENV_REF_MAX_DEG + j];
+        if (v != skip && graph_has(g, b, v)) out[m++] = v;
+    }
+    return m;
+}
+
+int meshenv_ref_smooth_final(RefEnv *e, int iteration, int32_t *sweeps_out, double *diff_out, int64_t *branch_out)
+{
+    if (e->n_elem > e->cap_e || e->n_vert > e->cap_v) return -1;
+    const int nv = e->n_vert, n0 = e->n0;
+    const double lr = 0.999;
+    Graph g;
+    g.adj = (int32_t *)malloc(sizeof(int32_t) * (size_t)nv * MESHENV_REF_MAX_DEG);
+    g.deg = (int32_t *)calloc((size_t)nv, sizeof(int32_t));
+    int32_t *nmesh = (int32_t *)calloc((size_t)nv, sizeof(int32_t));
+    uint8_t *on_front = (uint8_t *)calloc((size_t)nv, 1);
+    int rc = 0;
+    for (int i = 0; i < n0 && rc == 0; i++) { /* the domain ring's segments */
+        int a = (i + n0 - 1) % n0;
+        rc |= graph_add(&g, a, i);
+        rc |= graph_add(&g, i, a);
+    }
+    for (int k = 0; k < e->n_elem && rc == 0; k++) {
+        const int32_t *q = e->quads + 4 * k;
+        for (int i = 0; i < 4; i++) nmesh[q[i]] += 1;
+        for (int i = 0; i < 4 && rc == 0; i++) {
+            const int a = q[i], b = q[(i + 3) & 3];
+            if (graph_has(&g, a, b)) continue;
+            rc |= graph_add(&g, a, b);
+            rc |= graph_add(&g, b, a);
+        }
+    }
+    for (int i = 0; i < e->n; i++) on_front[e->rid[i]] = 1;
+    int64_t br[3] = {0, 0, 0};
+    double sum_coordinates = 0.0, diffs = 100.0;
+    int it = 0;
+    while (rc == 0 && diffs > 0.001 && it < iteration) {
+        it += 1;
+        for (int v = n0; v < nv && rc == 0; v++) {
+            const int d = g.deg[v];
+            const int32_t *cn = g.adj + v * MESHENV_REF_MAX_DEG;
+            const int nm = nmesh[v];
+            int pull = 0;
+            br[nm == 1 ? 0 : (nm == 2 ? 1 : 2)] += 1;
+            if (nm == 1) {
+                if (d == 2) {
+                    int com[MESHENV_REF_MAX_DEG];
+                    int m = common_vertices(&g, cn[0], cn[1], v, com);
+                    int origin = nearest_of(e, com, m, v);
+                    if (origin < 0) { rc = -2; break; }
+                    /* nearest front vertex to origin, not a neighbour of v and not v */
+                    int best = -1;
+                    double bd = 0.0;
+                    for (int i = 0; i < e->n; i++) {
+                        int w = e->rid[i];
+                        if (w == cn[0] || w == cn[1] || w == v || w == origin) continue; /* compute_dist skips the point itself */
+                        double dd = dist(e->vtab[origin], e->vtab[w]);
+                        if (best < 0 || dd < bd) { best = w; bd = dd; }
+                    }
+                    if (best < 0) continue;
+                    e->vtab[v] = estimate_4th_vertex(e->vtab[origin], e->vtab[cn[0]], e->vtab[cn[1]], 0.5, 1, bd);
+                } else {
+                    pull = 1;
+                }
+            } else if (nm == 2) {
+                int ub[MESHENV_REF_MAX_DEG], in[MESHENV_REF_MAX_DEG], nu = 0, ni = 0;
+                for (int j = 0; j < d; j++) {
+                    if (on_front[cn[j]]) ub[nu++] = cn[j];
+                    else in[ni++] = cn[j];
+                }
+                if (ni == 1 && nu == 2) {
+                    int com[MESHENV_REF_MAX_DEG];
+                    int m = common_vertices(&g, in[0], ub[0], v, com);
+                    int c1 = nearest_of(e, com, m, v);
+                    m = common_vertices(&g, in[0], ub[1], v, com);
+                    int c2 = nearest_of(e, com, m, v);
+                    if (c1 < 0 || c2 < 0) { rc = -2; break; }
+                    P2 e1 = estimate_4th_vertex(e->vtab[c1], e->vtab[ub[0]], e->vtab[in[0]], 0.7, 0, 0.0);
+                    P2 e2 = estimate_4th_vertex(e->vtab[c2], e->vtab[ub[1]], e->vtab[in[0]], 0.7, 0, 0.0);
+                    e->vtab[v].x = (e1.x + e2.x) / 2;
+                    e->vtab[v].y = (e1.y + e2.y) / 2;
+                } else {
+                    pull = 1;
+                }
+            } else {
+                if (d == 0) continue;
+                double x = 0.0, y = 0.0;
+                for (int j = 0; j < d; j++) {
+                    x += e->vtab[cn[j]].x + e->vtab[v].x;
+                    y += e->vtab[cn[j]].y + e->vtab[v].y;
+                }
+                e->vtab[v].x = x / (double)(2 * d);
+                e->vtab[v].y = y / (double)(2 * d);
+            }
+            if (pull)
+                for (int j = 0; j < d; j++) {
+                    e->vtab[v].x = lr * e->vtab[v].x + (1 - lr) * e->vtab[cn[j]].x;
+                    e->vtab[v].y = lr * e->vtab[v].y + (1 - lr) * e->vtab[cn[j]].y;
+                }
+        }
+        double new_sum = 0.0;
+        for (int v = 0; v < nv; v++) new_sum += e->vtab[v].x + e->vtab[v].y;
+        diffs = fabs(new_sum - sum_coordinates);
+        sum_coordinates = new_sum;
+    }
+    free(g.adj); free(g.deg); free(nmesh); free(on_front);
+    if (rc != 0) return rc;
+    /* front vertices may have moved: the ring holds copies */
+    for (int i = 0; i < e->n; i++) e->ring[i] = e->vtab[e->rid[i]];
+    find_reference_candidates(e); /* M:1392 */
+    if (sweeps_out) *sweeps_out = it;
+    if (diff_out) *diff_out = diffs;
+    if (branch_out) { branch_out[0] = br[0]; branch_out[1] = br[1]; branch_out[2] = br[2]; }
+    return 0;
+}
+
 int meshenv_ref_not_valid_count(const RefEnv *e) { return e->n_nv; }
 
 int meshenv_ref_ring_len(const RefEnv *e) { return e->n; }

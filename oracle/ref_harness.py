@@ -371,3 +371,75 @@ def record_smooth_trace(points, actions: np.ndarray, smooth_every: int, iteratio
             out["call_cand_ids"][k, :len(c["cand_ids"])] = c["cand_ids"]
             out["call_cand_keys"][k, :len(c["cand_keys"])] = c["cand_keys"]
     return out
+
+
+def record_final_smooth_trace(points, actions: np.ndarray, iteration: int = 400, max_calls: int = 64) -> dict:
+    """Drive step() and, whenever an episode ends COMPLETE (front of 4 or 5 vertices), call the reference's
+    smooth(boundary.vertices, iteration=...) (general/mesh.py:1290-1392: the call general/EBRD.py:391 makes on a finished
+    mesh) before resetting.  Recorded per call: vertex table before / after, element log, front, sweep count, and how
+    many vertex visits took each of smooth()'s three branches (1 / 2 / >= 3 related meshes)."""
+    import contextlib
+    import io
+    import re
+    env = make_env(points)
+    T = len(actions)
+    env.reset()
+
+    def ids_of(vlist):
+        table = {id(v): k for k, v in enumerate(env.boundary.vertices)}
+        return [table[id(v)] for v in vlist]
+
+    calls = []
+    done_flags = np.zeros(T, np.uint8)
+    complete_flags = np.zeros(T, np.uint8)
+    for t in range(T):
+        obs, rew, done, info = env.step(actions[t])
+        done_flags[t] = done
+        complete_flags[t] = info["is_complete"]
+        if done:
+            if info["is_complete"] and len(calls) < max_calls:
+                before = np.array([(v.x, v.y) for v in env.boundary.vertices], np.float64)
+                quads = np.array([ids_of(m.vertices) for m in env.generated_meshes], np.int32)
+                ring = np.array(ids_of(env.updated_boundary.vertices), np.int32)
+                branch = [0, 0, 0]
+                orig_frm = env.find_related_meshes
+
+                def counting(v, _f=orig_frm, _b=branch):
+                    r = _f(v)
+                    _b[min(len(r), 3) - 1 if len(r) else 2] += 1
+                    return r
+                env.find_related_meshes = counting
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    env.smooth(env.boundary.vertices, iteration=iteration)
+                env.find_related_meshes = orig_frm
+                m = re.search(r"Iteration numbers: (\d+), the diff of smoothing is ([-+0-9.e]+)!", buf.getvalue())
+                after = np.array([(v.x, v.y) for v in env.boundary.vertices], np.float64)
+                calls.append(dict(t=t, before=before, after=after, quads=quads, ring=ring, sweeps=int(m.group(1)),
+                                  diff=float(m.group(2)), branch=branch))
+            env.reset()
+    out = dict(domain_xy=np.array(points, np.float64), actions=actions, done=done_flags, complete=complete_flags,
+               consts=np.array([float(env.original_area), float(env.average_edge_length),
+                                float(env.estimated_area_range[0]), float(env.estimated_area_range[1])], np.float64),
+               n_calls=np.int32(len(calls)), iteration=np.int32(iteration))
+    if calls:
+        V = max(len(c["before"]) for c in calls)
+        E = max(len(c["quads"]) for c in calls)
+        R = max(len(c["ring"]) for c in calls)
+        nC = len(calls)
+        out.update(
+            call_t=np.array([c["t"] for c in calls], np.int32), call_sweeps=np.array([c["sweeps"] for c in calls], np.int32),
+            call_diff=np.array([c["diff"] for c in calls], np.float64),
+            call_branch=np.array([c["branch"] for c in calls], np.int64),
+            call_nv=np.array([len(c["before"]) for c in calls], np.int32),
+            call_ne=np.array([len(c["quads"]) for c in calls], np.int32),
+            call_nr=np.array([len(c["ring"]) for c in calls], np.int32),
+            call_before=np.full((nC, V, 2), np.nan), call_after=np.full((nC, V, 2), np.nan),
+            call_quads=np.full((nC, E, 4), -1, np.int32), call_ring=np.full((nC, R), -1, np.int32),
+        )
+        for k, c in enumerate(calls):
+            out["call_before"][k, :len(c["before"])] = c["before"]
+            out["call_after"][k, :len(c["after"])] = c["after"]
+            out["call_quads"][k, :len(c["quads"])] = c["quads"]
+            out["call_ring"][k, :len(c["ring"])] = c["ring"]
+    return out

@@ -44,6 +44,8 @@ def lib():
     L.meshenv_ref_move.argtypes = [C.c_void_p, _f64p, C.c_double, _f32p, _u8p, _u8p]
     L.meshenv_ref_smooth_interior.restype = C.c_int
     L.meshenv_ref_smooth_interior.argtypes = [C.c_void_p, C.c_int, _i32p, _f64p]
+    L.meshenv_ref_smooth_final.restype = C.c_int
+    L.meshenv_ref_smooth_final.argtypes = [C.c_void_p, C.c_int, _i32p, _f64p, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
     L.meshenv_ref_not_valid_count.restype = C.c_int
     L.meshenv_ref_not_valid_count.argtypes = [C.c_void_p]
     L.meshenv_ref_step.restype = C.c_int
@@ -148,6 +150,14 @@ class RefEnv:
         if self.L.meshenv_ref_smooth_interior(self.h, int(iteration), sw, df) != 0:
             raise RuntimeError("meshenv_ref_smooth_interior: element / vertex log overflow or vertex degree > 16")
         return int(sw[0]), float(df[0])
+
+    def smooth_final(self, iteration=400):
+        """smooth(boundary.vertices, iteration=iteration) of a finished mesh -> (sweeps, final diff, branch visits[3])."""
+        sw = np.zeros(1, np.int32); df = np.zeros(1, np.float64); br = np.zeros(3, np.int64)
+        rc = self.L.meshenv_ref_smooth_final(self.h, int(iteration), sw, df, br)
+        if rc != 0:
+            raise RuntimeError(f"meshenv_ref_smooth_final: code {rc} (-1 log / degree overflow, -2 the reference raises IndexError)")
+        return int(sw[0]), float(df[0]), br
 
     def not_valid_count(self):
         return int(self.L.meshenv_ref_not_valid_count(self.h))

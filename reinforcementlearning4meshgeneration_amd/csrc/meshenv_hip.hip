@@ -553,7 +553,7 @@ int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int inter
     }
     const size_t lds = smooth_lds_bytes(h->cap, log_cap);
     if (lds > 160 * 1024 || h->cap + log_cap > 65535)
-        return fail_arg(h, "meshenv_smooth: ring stride + log_capacity too large for the smoother's LDS (16 B per vertex + 34 B per logged vertex)");
+        return fail_arg(h, "meshenv_smooth: ring stride + log_capacity too large for the smoother's LDS (16 B per ring slot + 60 B per logged vertex)");
     MESHENV_ON_DEVICE(h);
     if (!h->smooth_sweeps) {
         const int rc = dev_alloc(h, &h->smooth_sweeps, (size_t)h->n_envs);

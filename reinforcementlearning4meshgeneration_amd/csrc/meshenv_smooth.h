@@ -15,13 +15,13 @@
 // The relaxation is Gauss-Seidel in boundary.vertices order (every vertex sees the new position of its predecessors),
 // each coordinate accumulated term by term as x += (neighbour.x + vertex.x); the sweeps stop when the running sum of the
 // moved vertices' x + y differs from the previous sweep's by <= 0.001, or after `iteration` sweeps.  Bit parity with that
-// needs the same order of the same additions, so a sweep is serial per env by definition of the algorithm; what runs in
-// parallel is envs (one wavefront each) and, inside a wavefront, the neighbour gather of the vertex being moved (one lane
-// per neighbour: index and coordinates from LDS in two reads, the term neighbour + vertex in parallel, then the ordered
-// sum over <= 16 lanes through v_readlane).  The graph (neighbour indices, 16 x uint16 per generated vertex) is built in
-// LDS by one lane per generated vertex scanning the element log, and the coordinates of the domain ring and of the
-// generated vertices sit in one LDS array, so that a sweep touches no HBM: HBM traffic is the logs once in, the moved
-// coordinates once out.
+// needs the same additions in the same order with the same operands.  One wavefront per env; inside it a sweep runs level
+// by level (k_smooth_interior: level = longest path from below in the list order, so that a level's vertices are mutually
+// non-adjacent and see exactly what the serial sweep would have shown them), one lane per vertex of the level, each lane
+// summing its own <= 16 neighbours in list order; only the stop rule's running sum is a serial chain (v_readlane per
+// vertex).  The graph (16 x uint16 per generated vertex) is built in LDS by one lane per generated vertex scanning the
+// element log, and the coordinates of the domain ring and of the generated vertices sit in one LDS array, so that a sweep
+// touches no HBM: HBM traffic is the logs once in, the moved coordinates once out.
 #pragma once
 
 #include "meshenv_kernels.h"
@@ -32,10 +32,11 @@ constexpr int kSmoothMaxDeg = 16;   // neighbours per generated vertex (a quad-m
 
 enum { kSmoothSkipped = -1, kSmoothLogOverflow = -2, kSmoothDegree = -3 };
 
-// LDS: coord[n0_max + log_cap] double2 | adj[log_cap][16] uint16 | deg[log_cap] uint8 | front[log_cap] uint8
+// LDS: coord[ring_cap + log_cap] double2 | xy_sum[log_cap] double | adj[log_cap][16] uint16 | lvl[log_cap] uint16 |
+//      deg[log_cap] uint8 | front[log_cap] uint8
 __host__ __device__ __forceinline__ size_t smooth_lds_bytes(int ring_cap, int log_cap)
 {
-    return (size_t)(ring_cap + log_cap) * sizeof(double2) + (size_t)log_cap * (kSmoothMaxDeg * 2 + 2) + 64;
+    return (size_t)(ring_cap + log_cap) * sizeof(double2) + (size_t)log_cap * (8 + kSmoothMaxDeg * 2 + 2 + 2) + 64;
 }
 
 // One wavefront per env.  sweeps_out[env]: sweeps made (>= 1 when a vertex could move; 1 with nothing to move, as the
@@ -67,8 +68,10 @@ k_smooth_interior(DevState S, int ring_cap, const uint8_t *__restrict__ mask, in
     double2 *vnew = cold.log_vxy + lbase;
 
     double2 *coord = smem;                                              // [0, n0): domain ring, [n0, n0 + n_new): generated
-    unsigned short *adj = (unsigned short *)(coord + ring_cap + log_cap);
-    unsigned char *deg = (unsigned char *)(adj + (size_t)log_cap * kSmoothMaxDeg);
+    double *xy_sum = (double *)(coord + ring_cap + log_cap);             // x + y of a moved vertex (the stop rule's terms)
+    unsigned short *adj = (unsigned short *)(xy_sum + log_cap);
+    unsigned short *lvl = adj + (size_t)log_cap * kSmoothMaxDeg;         // 0: does not move
+    unsigned char *deg = (unsigned char *)(lvl + log_cap);
     unsigned char *front = deg + log_cap;
 
     for (int i = lane; i < n0; i += 64) coord[i] = cold.dom_xy[doff + i];
@@ -127,31 +130,62 @@ k_smooth_interior(DevState S, int ring_cap, const uint8_t *__restrict__ mask, in
         return;
     }
     wave_sync();
+    // Levels of the Gauss-Seidel order.  In list order vertex v reads the NEW position of an adjacent u < v and the OLD one
+    // of an adjacent u > v; with level(v) = 1 + max level(u) over the movable neighbours u < v (longest path from below) no
+    // two vertices of a level are adjacent, lower levels are finished and higher ones untouched when a level runs -- so a
+    // level can be relaxed by one lane per vertex with exactly the values the serial sweep would have read.  (Monotone
+    // fixpoint iteration from 1: the order of the updates inside a pass does not matter.)
+    for (int k = lane; k < n_new; k += 64) lvl[k] = (front[k] == 0 && deg[k] != 0) ? 1 : 0;
+    wave_sync();
+    for (int pass = 0; pass <= n_new; pass++) {
+        bool changed = false;
+        for (int k = lane; k < n_new; k += 64) {
+            const int cur = lvl[k];
+            if (cur == 0) continue;
+            int m = 0;
+            const int d = deg[k];
+            for (int j = 0; j < d; j++) {
+                const int u = (int)adj[(size_t)k * kSmoothMaxDeg + j] - n0;
+                if (u >= 0 && u < k) { const int lu = lvl[u]; m = lu > m ? lu : m; }
+            }
+            if (m + 1 != cur) { lvl[k] = (unsigned short)(m + 1); changed = true; }
+        }
+        wave_sync();
+        if (__ballot(changed) == 0ULL) break;
+    }
+    int my_max = 0;
+    for (int k = lane; k < n_new; k += 64) my_max = lvl[k] > my_max ? lvl[k] : my_max;
+    const int n_levels = wave_max_i32(my_max);
     // smooth_fixed_vertices, M:1258-1288
     double sum_coordinates = 0.0, diffs = 100.0;
     int it = 0;
     while (diffs > 0.001 && it < iteration) {
         it += 1;
-        double new_sum = 0.0;
-        for (int k = 0; k < n_new; k++) {
-            const int d = uniform_i32((int)deg[k]);
-            if (uniform_i32((int)front[k]) != 0 || d == 0) continue;
-            const double2 v = coord[n0 + k];
-            double tx = 0.0, ty = 0.0;
-            if (lane < d) {
-                const double2 c = coord[adj[(size_t)k * kSmoothMaxDeg + lane]];
-                tx = c.x + v.x;
-                ty = c.y + v.y;
+        for (int l = 1; l <= n_levels; l++) {
+            for (int k = lane; k < n_new; k += 64) {
+                if (lvl[k] != l) continue;
+                const int d = deg[k];
+                const double2 v = coord[n0 + k];
+                double x = 0.0, y = 0.0;   // the reference starts from an int 0
+                for (int j = 0; j < d; j++) {
+                    const double2 c = coord[adj[(size_t)k * kSmoothMaxDeg + j]];
+                    x += c.x + v.x;
+                    y += c.y + v.y;
+                }
+                const double nx = x / (double)(2 * d), ny = y / (double)(2 * d);
+                coord[n0 + k] = make_double2(nx, ny);   // read by no vertex of this level
+                xy_sum[k] = nx + ny;
             }
-            double x = 0.0 + lane_f64(tx, 0), y = 0.0 + lane_f64(ty, 0);   // the reference starts from an int 0
-            for (int j = 1; j < d; j++) {
-                x += lane_f64(tx, j);
-                y += lane_f64(ty, j);
-            }
-            const double nx = x / (double)(2 * d), ny = y / (double)(2 * d);
-            if (lane == 0) coord[n0 + k] = make_double2(nx, ny);
-            new_sum += nx + ny;
             wave_sync();
+        }
+        // new_sum_coordinates += vertex.x + vertex.y in list order; a vertex that does not move adds nothing (an exact
+        // + 0.0 here: the running sum starts at +0 and can never become -0)
+        double new_sum = 0.0;
+        for (int k0 = 0; k0 < n_new; k0 += 64) {
+            const int k = k0 + lane;
+            const double sv = (k < n_new && lvl[k] != 0) ? xy_sum[k] : 0.0;
+            const int m = n_new - k0 < 64 ? n_new - k0 : 64;
+            for (int j = 0; j < m; j++) new_sum += lane_f64(sv, j);
         }
         diffs = fabs(new_sum - sum_coordinates);
         sum_coordinates = new_sum;

@@ -17,7 +17,7 @@ def pytest_configure(config):
 def golden_names():
     """Recorded reference traces (quality_*.npz holds element records, not a trace)."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
-                  if f.endswith(".npz") and not f.startswith(("quality_", "move_", "smooth_")))
+                  if f.endswith(".npz") and not f.startswith(("quality_", "move_", "smooth")))
 
 
 def move_golden_names():
@@ -28,6 +28,11 @@ def move_golden_names():
 def smooth_golden_names():
     """Recorded step() traces with smooth_pave(interior=True) calls in between (oracle/gen_golden.py --smooth-only)."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("smooth_"))
+
+
+def final_smooth_golden_names():
+    """Recorded smooth() calls of the reference on finished meshes (oracle/gen_golden.py --smooth-only)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("smoothfinal_"))
 
 
 @pytest.fixture(scope="session")

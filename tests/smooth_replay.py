@@ -46,3 +46,29 @@ def replay(tr, impl, obs_tol=0.0, exact_vertices=True, key_tol=0.0):
             assert np.array_equal(ids, tr["call_cand_ids"][k, :nc]), t
             assert np.abs(keys - tr["call_cand_keys"][k, :nc]).max(initial=0.0) <= key_tol, t
     return moved_total
+
+
+def replay_final(tr, impl, vertex_tol=0.0):
+    """smoothfinal_*.npz: step() until an episode ends complete, then smooth() (general/mesh.py:1290-1392) before the reset.
+    impl as above plus impl.smooth_final(iteration) -> sweeps.  Returns the largest vertex deviation seen."""
+    calls = {int(t): k for k, t in enumerate(tr["call_t"])}
+    iteration = int(tr["iteration"])
+    impl.reset()
+    worst = 0.0
+    for t in range(len(tr["actions"])):
+        o, r, d, c = impl.step(tr["actions"][t])
+        assert bool(d) == bool(tr["done"][t]) and bool(c) == bool(tr["complete"][t]), t
+        if t in calls:
+            k = calls[t]
+            nv, ne, nr = (int(tr[x][k]) for x in ("call_nv", "call_ne", "call_nr"))
+            assert np.array_equal(impl.elements(), tr["call_quads"][k, :ne]), t
+            assert np.array_equal(impl.ring_ids(), tr["call_ring"][k, :nr]), t
+            assert np.array_equal(impl.vertices(), tr["call_before"][k, :nv]), t
+            sweeps = impl.smooth_final(iteration)
+            assert sweeps == int(tr["call_sweeps"][k]), (t, sweeps, int(tr["call_sweeps"][k]))
+            dev = float(np.abs(impl.vertices() - tr["call_after"][k, :nv]).max())
+            assert dev <= vertex_tol, (t, dev)
+            worst = max(worst, dev)
+        if d:
+            impl.reset()
+    return worst

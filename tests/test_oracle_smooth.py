@@ -6,8 +6,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_DIR, smooth_golden_names
-from smooth_replay import replay
+from conftest import GOLDEN_DIR, final_smooth_golden_names, smooth_golden_names
+from smooth_replay import replay, replay_final
 
 
 class OracleImpl:
@@ -25,6 +25,9 @@ class OracleImpl:
 
     def smooth(self, iteration):
         return self.env.smooth_interior(iteration)[0]
+
+    def smooth_final(self, iteration):
+        return self.env.smooth_final(iteration)[0]
 
     def vertices(self):
         return self.env.elements()[1]
@@ -52,3 +55,21 @@ def test_smooth_fixtures_cover_both_stop_rules():
     assert any(((t["call_sweeps"] > 1) & (t["call_sweeps"] < int(t["iteration"]))).any() for t in trs)   # by the 0.001 rule
     assert any((t["call_sweeps"] >= 40).any() for t in trs)
     assert any((t["call_nv"] - t["domain_xy"].shape[0] >= 30).any() for t in trs)   # dozens of generated vertices
+
+
+@pytest.mark.parametrize("name", final_smooth_golden_names())
+def test_oracle_smooth_of_finished_meshes_matches_reference_records(name):
+    """MeshGeneration.smooth (general/mesh.py:1290-1392) on episodes that ended complete: same sweep counts, vertex table
+    bit-identical (the two estimate branches call atan2 / cos / sin: the same libm as the recording interpreter here)."""
+    tr = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    assert int(tr["n_calls"]) >= 3
+    replay_final(tr, OracleImpl(tr), vertex_tol=0.0)
+
+
+def test_final_smooth_fixtures_cover_all_three_branches_and_both_front_sizes():
+    trs = [dict(np.load(os.path.join(GOLDEN_DIR, n + ".npz"))) for n in final_smooth_golden_names()]
+    visits = np.sum([t["call_branch"].sum(axis=0) for t in trs], axis=0)
+    assert (visits > 50).all(), visits                    # 1 / 2 / >= 3 related elements
+    fronts = np.concatenate([t["call_nr"] for t in trs])
+    assert (fronts == 4).any() and (fronts == 5).any()
+    assert any((t["call_sweeps"] == int(t["iteration"])).any() for t in trs)
