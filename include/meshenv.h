@@ -219,8 +219,23 @@ int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, f
  *              MESHENV_SMOOTH_DEGREE (a vertex with more than 16 neighbours) leave the env untouched
  *   diff_dev   [n_envs] float64, nullable: the last |sum - previous sum| (what the reference prints)
  * interior = 0 (smooth_current_boundary_3 on the front itself, general/mesh.py:939-1028) is not built: MESHENV_E_ARG. */
-enum { MESHENV_SMOOTH_SKIPPED = -1, MESHENV_SMOOTH_LOG_OVERFLOW = -2, MESHENV_SMOOTH_DEGREE = -3 };
+enum {
+    MESHENV_SMOOTH_SKIPPED = -1, MESHENV_SMOOTH_LOG_OVERFLOW = -2, MESHENV_SMOOTH_DEGREE = -3,
+    MESHENV_SMOOTH_NOT_FINISHED = -4, /* meshenv_smooth_final on a front of more than 5 vertices */
+    MESHENV_SMOOTH_INDEX_ERROR = -5   /* the reference raises IndexError here (empty common-neighbour list) */
+};
 int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int interior, int32_t *sweeps_dev, double *diff_dev);
+
+/* MeshGeneration.smooth(boundary.vertices, lr_1, lr_2, iteration), general/mesh.py:1290-1392 -- the post-processing of a
+ * FINISHED mesh (general/EBRD.py:391: front of <= 5 vertices) -- on every env with mask_dev[e] != 0 whose running episode
+ * has ended and has not been reset (step with auto_reset = 0, smooth, read the mesh, reset): every generated vertex, front
+ * vertices included, by the number of elements around it -- 4th-vertex estimates for 1 and 2 (general/mesh.py:1305-1361),
+ * the Laplacian step otherwise -- until the coordinate sum of the whole vertex list changes by <= 0.001 or `iteration`
+ * sweeps.  The reference's defaults are lr_1 = lr_2 = 0.999, iteration = 400.  The vertex log and the front's coordinates
+ * hold the result; the candidate list of the (finished) episode is not rebuilt -- the next call on such an env is a reset.
+ * sweeps_dev / diff_dev as meshenv_smooth, plus MESHENV_SMOOTH_NOT_FINISHED and MESHENV_SMOOTH_INDEX_ERROR (env untouched). */
+int meshenv_smooth_final(MeshEnv *h, const uint8_t *mask_dev, int iteration, double lr_1, double lr_2, int32_t *sweeps_dev,
+                         double *diff_dev);
 
 /* Host-side readout of one env's not_valid_points (synchronises the stream): xy_host[2*cap_points], *count = length. */
 int meshenv_get_not_valid(MeshEnv *h, int env, double *xy_host, int cap_points, int32_t *count);

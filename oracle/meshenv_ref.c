@@ -1036,11 +1036,11 @@ static int common_vertices(const Graph *g, int a, int b, int skip, int *out)
     return m;
 }
 
-int meshenv_ref_smooth_final(RefEnv *e, int iteration, int32_t *sweeps_out, double *diff_out, int64_t *branch_out)
+int meshenv_ref_smooth_final(RefEnv *e, int iteration, double lr_1, double lr_2, int32_t *sweeps_out, double *diff_out,
+                             int64_t *branch_out)
 {
     if (e->n_elem > e->cap_e || e->n_vert > e->cap_v) return -1;
     const int nv = e->n_vert, n0 = e->n0;
-    const double lr = 0.999;
     Graph g;
     g.adj = (int32_t *)malloc(sizeof(int32_t) * (size_t)nv * MESHENV_REF_MAX_DEG);
     g.deg = (int32_t *)calloc((size_t)nv, sizeof(int32_t));
@@ -1124,11 +1124,13 @@ int meshenv_ref_smooth_final(RefEnv *e, int iteration, int32_t *sweeps_out, doub
                 e->vtab[v].x = x / (double)(2 * d);
                 e->vtab[v].y = y / (double)(2 * d);
             }
-            if (pull)
+            if (pull) {
+                const double lr = nm == 1 ? lr_1 : lr_2;
                 for (int j = 0; j < d; j++) {
                     e->vtab[v].x = lr * e->vtab[v].x + (1 - lr) * e->vtab[cn[j]].x;
                     e->vtab[v].y = lr * e->vtab[v].y + (1 - lr) * e->vtab[cn[j]].y;
                 }
+            }
         }
         double new_sum = 0.0;
         for (int v = 0; v < nv; v++) new_sum += e->vtab[v].x + e->vtab[v].y;

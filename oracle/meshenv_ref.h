@@ -62,7 +62,8 @@ void meshenv_ref_get_ring(const RefEnv *e, int32_t *ids, double *xy);
 int meshenv_ref_smooth_interior(RefEnv *e, int iteration, int32_t *sweeps_out, double *diff_out);
 /* MeshGeneration.smooth(boundary.vertices, iteration=...), general/mesh.py:1290-1392 (finished meshes, general/EBRD.py:391);
  * branch_out[3]: vertex visits with 1 / 2 / other numbers of related elements; -2 = the reference raises IndexError */
-int meshenv_ref_smooth_final(RefEnv *e, int iteration, int32_t *sweeps_out, double *diff_out, int64_t *branch_out);
+int meshenv_ref_smooth_final(RefEnv *e, int iteration, double lr_1, double lr_2, int32_t *sweeps_out, double *diff_out,
+                             int64_t *branch_out);
 /* candidate list in the reference's list order: (key asc, insertion desc) */
 int meshenv_ref_get_candidates(const RefEnv *e, int32_t *ids, double *keys);
 int meshenv_ref_ref_id(const RefEnv *e);

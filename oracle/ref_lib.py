@@ -45,7 +45,8 @@ def lib():
     L.meshenv_ref_smooth_interior.restype = C.c_int
     L.meshenv_ref_smooth_interior.argtypes = [C.c_void_p, C.c_int, _i32p, _f64p]
     L.meshenv_ref_smooth_final.restype = C.c_int
-    L.meshenv_ref_smooth_final.argtypes = [C.c_void_p, C.c_int, _i32p, _f64p, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
+    L.meshenv_ref_smooth_final.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, _i32p, _f64p,
+                                           np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
     L.meshenv_ref_not_valid_count.restype = C.c_int
     L.meshenv_ref_not_valid_count.argtypes = [C.c_void_p]
     L.meshenv_ref_step.restype = C.c_int
@@ -151,10 +152,10 @@ class RefEnv:
             raise RuntimeError("meshenv_ref_smooth_interior: element / vertex log overflow or vertex degree > 16")
         return int(sw[0]), float(df[0])
 
-    def smooth_final(self, iteration=400):
+    def smooth_final(self, iteration=400, lr_1=0.999, lr_2=0.999):
         """smooth(boundary.vertices, iteration=iteration) of a finished mesh -> (sweeps, final diff, branch visits[3])."""
         sw = np.zeros(1, np.int32); df = np.zeros(1, np.float64); br = np.zeros(3, np.int64)
-        rc = self.L.meshenv_ref_smooth_final(self.h, int(iteration), sw, df, br)
+        rc = self.L.meshenv_ref_smooth_final(self.h, int(iteration), float(lr_1), float(lr_2), sw, df, br)
         if rc != 0:
             raise RuntimeError(f"meshenv_ref_smooth_final: code {rc} (-1 log / degree overflow, -2 the reference raises IndexError)")
         return int(sw[0]), float(df[0]), br

@@ -13,7 +13,7 @@ ACT_DIM = 3
 ST_NO_REFERENCE = 1
 ST_LOG_OVERFLOW = 2
 MOVE_OK, MOVE_NONE, MOVE_RAISES, MOVE_NEEDS_SMOOTHING = 0, 1, 2, 3
-SMOOTH_SKIPPED, SMOOTH_LOG_OVERFLOW, SMOOTH_DEGREE = -1, -2, -3
+SMOOTH_SKIPPED, SMOOTH_LOG_OVERFLOW, SMOOTH_DEGREE, SMOOTH_NOT_FINISHED, SMOOTH_INDEX_ERROR = -1, -2, -3, -4, -5
 
 
 class MeshEnvParams(C.Structure):
@@ -41,7 +41,7 @@ EXPORTS = [
     "meshenv_actor_create", "meshenv_actor_destroy", "meshenv_actor_set_stream", "meshenv_actor_load",
     "meshenv_actor_forward", "meshenv_actor_sample", "meshenv_get_last_episode", "meshenv_element_quality",
     "meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid", "meshenv_step_kernel",
-    "meshenv_create_random", "meshenv_get_domain", "meshenv_smooth",
+    "meshenv_create_random", "meshenv_get_domain", "meshenv_smooth", "meshenv_smooth_final",
 ]
 
 
@@ -99,6 +99,8 @@ def load():
     L.meshenv_get_not_valid.argtypes = [vp, C.c_int, vp, C.c_int, i32p]
     L.meshenv_smooth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     L.meshenv_smooth.restype = C.c_int
+    L.meshenv_smooth_final.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, vp, vp]
+    L.meshenv_smooth_final.restype = C.c_int
     L.meshenv_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.meshenv_rollout.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
     L.meshenv_get_status.argtypes = [vp, vp]

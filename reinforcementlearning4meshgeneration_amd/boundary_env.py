@@ -103,6 +103,19 @@ class BoudaryEnv:  # the reference's spelling
         sweeps, _ = self._vec.smooth_pave(iteration=iteration, interior=interior)
         return int(sweeps.cpu()[0])
 
+    def smooth(self, vertices=None, lr_1=0.999, lr_2=0.999, iteration=400):
+        """MeshGeneration.smooth, general/mesh.py:1290-1392, on a finished episode (general/EBRD.py:391); `vertices` is
+        implied (boundary.vertices).  Returns the number of sweeps; raises where the reference raises IndexError, and
+        RuntimeError if the episode is still running (front > 5)."""
+        from . import _capi
+        sweeps, _ = self._vec.smooth(lr_1=lr_1, lr_2=lr_2, iteration=iteration)
+        n = int(sweeps.cpu()[0])
+        if n == _capi.SMOOTH_INDEX_ERROR:
+            raise IndexError("list index out of range (smooth(): a vertex without a common neighbour, as in the reference)")
+        if n < 0:
+            raise RuntimeError(f"smooth(): not applicable to this episode (code {n}: see _capi.SMOOTH_*)")
+        return n
+
     @property
     def not_valid_points(self):
         """[k, 2] coordinates of the reference vertices rejected since the last valid move (rl/boundary_env.py:47)."""

@@ -49,6 +49,7 @@ struct MeshEnv {
     Reselect *pend = nullptr;          // [E] selection parked by the candidate rebuild (csrc/meshenv_smooth.h)
     float *pend_obs = nullptr;         // [E][18]
     bool reselect_pending = false;     // a rebuild ran since the last step kernel
+    bool smooth_final_ready = false;
     // move() API state, allocated by the first meshenv_move: not_valid_points per env
     double2 *nv_xy = nullptr;    // [E][cap]
     int32_t *nv_count = nullptr; // [E]
@@ -573,6 +574,30 @@ int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int inter
                        h->pend_obs);
     HIP_TRY(h, hipGetLastError());
     h->reselect_pending = true;
+    return MESHENV_OK;
+}
+
+int meshenv_smooth_final(MeshEnv *h, const uint8_t *mask_dev, int iteration, double lr_1, double lr_2, int32_t *sweeps_dev,
+                         double *diff_dev)
+{
+    if (!h) return MESHENV_E_ARG;
+    if (iteration < 0) return fail_arg(h, "meshenv_smooth_final: iteration must be >= 0");
+    const int log_cap = h->S.prm.log_cap;
+    if (log_cap <= 0) {
+        h->err = "meshenv_smooth_final: handle was created with log_capacity = 0 (the mesh graph is rebuilt from the element log)";
+        return MESHENV_E_STATE;
+    }
+    const size_t lds = smooth_final_lds_bytes(h->cap, log_cap);
+    if (lds > 160 * 1024 || h->cap + log_cap > 65535)
+        return fail_arg(h, "meshenv_smooth_final: ring stride + log_capacity too large for the smoother's LDS (51 B per vertex)");
+    MESHENV_ON_DEVICE(h);
+    if (!h->smooth_final_ready) {
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_smooth_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        h->smooth_final_ready = true;
+    }
+    hipLaunchKernelGGL(k_smooth_final, dim3(h->n_envs), dim3(64), lds, h->stream, h->S, h->cap, mask_dev, iteration, lr_1, lr_2,
+                       sweeps_dev, diff_dev);
+    HIP_TRY(h, hipGetLastError());
     return MESHENV_OK;
 }
 

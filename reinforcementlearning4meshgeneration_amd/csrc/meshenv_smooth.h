@@ -30,13 +30,71 @@ namespace meshenv {
 
 constexpr int kSmoothMaxDeg = 16;   // neighbours per generated vertex (a quad-mesh vertex has 3-6; more sets code -3)
 
-enum { kSmoothSkipped = -1, kSmoothLogOverflow = -2, kSmoothDegree = -3 };
+enum { kSmoothSkipped = -1, kSmoothLogOverflow = -2, kSmoothDegree = -3, kSmoothNotFinished = -4, kSmoothIndexError = -5 };
 
 // LDS: coord[ring_cap + log_cap] double2 | xy_sum[log_cap] double | adj[log_cap][16] uint16 | lvl[log_cap] uint16 |
 //      deg[log_cap] uint8 | front[log_cap] uint8
 __host__ __device__ __forceinline__ size_t smooth_lds_bytes(int ring_cap, int log_cap)
 {
     return (size_t)(ring_cap + log_cap) * sizeof(double2) + (size_t)log_cap * (8 + kSmoothMaxDeg * 2 + 2 + 2) + 64;
+}
+
+// Vertex.segments as neighbour lists, for the vertices first .. first + count - 1 (unified index: domain vertex i -> i,
+// k-th generated vertex -> n0 + k), one lane per vertex, every lane scanning the element log in order (all lanes read
+// the same 16-byte record).  Row r = vertex first + r: adj[r][0 .. deg[r]), n_mesh[r] (nullable) = elements that contain
+// it.  A domain vertex starts with its two ring segments in the order general/mesh.py:1926-1930 creates them.  Returns
+// true (per lane) when a vertex has more than kSmoothMaxDeg neighbours.
+__device__ __forceinline__ bool build_segment_lists(const int4 *__restrict__ quads, int n_elem, int n0, int first, int count,
+                                                    unsigned short *adj, unsigned char *deg, unsigned char *n_mesh)
+{
+    const int lane = lane_id();
+    bool too_many = false;
+    for (int r0 = 0; r0 < count; r0 += 64) {
+        const int r = r0 + lane, u_me = first + r;
+        const int me = u_me >= n0 ? (kNewBit | (u_me - n0)) : u_me;
+        unsigned short mine[kSmoothMaxDeg] = {};
+        int d = 0, nm = 0;
+        if (u_me < n0) {  // for i in range(n0): Segment(v[i-1], v[i]) is appended to v[i-1], then to v[i]
+            const int prev = u_me == 0 ? n0 - 1 : u_me - 1, next = u_me == n0 - 1 ? 0 : u_me + 1;
+            mine[0] = (unsigned short)(u_me == n0 - 1 ? next : prev);
+            mine[1] = (unsigned short)(u_me == n0 - 1 ? prev : next);
+            d = 2;
+        }
+        for (int e = 0; e < n_elem; e++) {
+            const int4 q = quads[e];
+            const int p = q.x == me ? 0 : (q.y == me ? 1 : (q.z == me ? 2 : (q.w == me ? 3 : -1)));
+            if (p < 0 || r >= count) continue;
+            nm += 1;
+            // pairs (i, i-1) for i = 0..3 that contain position p, in the order of i
+            const int first_g = p == 0 ? q.w : (p == 1 ? q.x : (p == 2 ? q.y : q.x));
+            const int second_g = p == 0 ? q.y : (p == 1 ? q.z : (p == 2 ? q.w : q.z));
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int g = s == 0 ? first_g : second_g;
+                const unsigned short u = (unsigned short)((g & kNewBit) ? n0 + (g & ~kNewBit) : g);
+                bool have = false;
+#pragma unroll
+                for (int j = 0; j < kSmoothMaxDeg; j++) have = have || (j < d && mine[j] == u);
+                if (!have) {
+                    if (d < kSmoothMaxDeg) {
+#pragma unroll
+                        for (int j = 0; j < kSmoothMaxDeg; j++)
+                            if (j == d) mine[j] = u;
+                        d += 1;
+                    } else {
+                        too_many = true;
+                    }
+                }
+            }
+        }
+        if (r < count) {
+#pragma unroll
+            for (int j = 0; j < kSmoothMaxDeg; j++) adj[(size_t)r * kSmoothMaxDeg + j] = mine[j];
+            deg[r] = (unsigned char)d;
+            if (n_mesh) n_mesh[r] = (unsigned char)(nm > 255 ? 255 : nm);
+        }
+    }
+    return too_many;
 }
 
 // One wavefront per env.  sweeps_out[env]: sweeps made (>= 1 when a vertex could move; 1 with nothing to move, as the
@@ -87,44 +145,7 @@ k_smooth_interior(DevState S, int ring_cap, const uint8_t *__restrict__ mask, in
         if (g & kNewBit) front[g & ~kNewBit] = 1;
     }
     // the neighbour lists: one lane per generated vertex, the element log read by all lanes at the same address
-    bool too_many = false;
-    for (int k0 = 0; k0 < n_new; k0 += 64) {
-        const int k = k0 + lane;
-        const int me = kNewBit | k;
-        unsigned short mine[kSmoothMaxDeg] = {};
-        int d = 0;
-        for (int e = 0; e < n_elem; e++) {
-            const int4 q = quads[e];
-            const int p = q.x == me ? 0 : (q.y == me ? 1 : (q.z == me ? 2 : (q.w == me ? 3 : -1)));
-            if (p < 0 || k >= n_new) continue;
-            // pairs (i, i-1) for i = 0..3 that contain position p, in the order of i
-            const int first = p == 0 ? q.w : (p == 1 ? q.x : (p == 2 ? q.y : q.x));
-            const int second = p == 0 ? q.y : (p == 1 ? q.z : (p == 2 ? q.w : q.z));
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const int g = s == 0 ? first : second;
-                const unsigned short u = (unsigned short)((g & kNewBit) ? n0 + (g & ~kNewBit) : g);
-                bool have = false;
-#pragma unroll
-                for (int j = 0; j < kSmoothMaxDeg; j++) have = have || (j < d && mine[j] == u);
-                if (!have) {
-                    if (d < kSmoothMaxDeg) {
-#pragma unroll
-                        for (int j = 0; j < kSmoothMaxDeg; j++)
-                            if (j == d) mine[j] = u;
-                        d += 1;
-                    } else {
-                        too_many = true;
-                    }
-                }
-            }
-        }
-        if (k < n_new) {
-#pragma unroll
-            for (int j = 0; j < kSmoothMaxDeg; j++) adj[(size_t)k * kSmoothMaxDeg + j] = mine[j];
-            deg[k] = (unsigned char)d;
-        }
-    }
+    const bool too_many = build_segment_lists(quads, n_elem, n0, n0, n_new, adj, deg, nullptr);
     if (__ballot(too_many) != 0ULL) {
         if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothDegree;
         return;
@@ -193,6 +214,239 @@ k_smooth_interior(DevState S, int ring_cap, const uint8_t *__restrict__ mask, in
     for (int k = lane; k < n_new; k += 64)
         if (front[k] == 0 && deg[k] != 0) vnew[k] = coord[n0 + k];
     if (lane == 0) {
+        if (sweeps_out) sweeps_out[env] = it;
+        if (diff_out) diff_out[env] = diffs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ finished meshes: smooth()
+//
+// MeshGeneration.smooth(boundary.vertices, iteration=...), general/mesh.py:1290-1392 -- what general/EBRD.py:391 runs once
+// an episode has ended with a front of <= 5 vertices.  Every generated vertex, in list order, by the number of elements
+// that contain it: 1 -> (two neighbours) the 4th-vertex estimate from their common neighbour, else a 0.999 pull towards
+// each neighbour in turn; 2 -> (one interior + two front neighbours) the mean of two 4th-vertex estimates, else the pull;
+// otherwise the Laplacian step of smooth_fixed_vertices.  Front vertices move too, the stop rule sums x + y over the whole
+// vertex list.  The estimate branches read two-hop neighbourhoods and the front, so the sweep is run in list order by the
+// whole wavefront (wave-uniform control flow, LDS broadcast reads; the Laplacian gather and the front scan use the
+// lanes); the graph holds the domain vertices' lists as well (get_common_vertex walks them).
+
+__host__ __device__ __forceinline__ size_t smooth_final_lds_bytes(int ring_cap, int log_cap)
+{
+    const size_t V = (size_t)ring_cap + log_cap;
+    return V * sizeof(double2) + V * kSmoothMaxDeg * 2 + (size_t)ring_cap * 2 + V * 3 + 64;
+}
+
+struct SmoothGraph {
+    const double2 *coord;
+    const unsigned short *adj;
+    const unsigned char *deg;
+};
+
+__device__ __forceinline__ bool graph_has(const SmoothGraph &g, int v, int w)
+{
+    const int d = uniform_i32((int)g.deg[v]);
+    bool have = false;
+    for (int j = 0; j < d; j++) have = have || (int)g.adj[(size_t)v * kSmoothMaxDeg + j] == w;
+    return have;
+}
+
+// Boundary2D.compute_dist([v for v in a.get_common_vertex(b) if v is not skip], point)[0][0], C:162-165,369-376: of the
+// neighbours of a (in a's list order) that are also neighbours of b, the nearest to `point` (first among equals); -1: none
+__device__ __forceinline__ int nearest_common(const SmoothGraph &g, int a, int b, int skip, int point)
+{
+    const int da = uniform_i32((int)g.deg[a]);
+    const double2 pp = g.coord[point];
+    int best = -1;
+    double bd = 0.0;
+    for (int j = 0; j < da; j++) {
+        const int w = uniform_i32((int)g.adj[(size_t)a * kSmoothMaxDeg + j]);
+        if (w == skip || !graph_has(g, b, w)) continue;
+        const double2 cw_ = g.coord[w];
+        const double dd = dist(mkp(pp.x, pp.y), mkp(cw_.x, cw_.y));
+        if (best < 0 || dd < bd) { best = w; bd = dd; }
+    }
+    return best;
+}
+
+// Mesh.estimate_4th_vertex, C:980-990 -> Segment.get_ray_segment / build_ray, C:588-610
+__device__ __forceinline__ double2 estimate_4th_vertex(double2 origin, double2 left, double2 right, double factor,
+                                                       bool has_suggest, double suggest_dist)
+{
+    const P2 o = mkp(origin.x, origin.y);
+    double distance = (dist(o, mkp(left.x, left.y)) + dist(o, mkp(right.x, right.y))) * factor;
+    if (has_suggest) {
+        const double lim = 0.6 * suggest_dist;
+        distance = lim < distance ? lim : distance;
+    }
+    const double r1x = (origin.x + origin.x) / 2, r1y = (origin.y + origin.y) / 2;
+    const double r2x = (left.x + right.x) / 2, r2y = (left.y + right.y) / 2;
+    const SinCos sc = sincos_nc(atan2_nc(r2y - r1y, r2x - r1x));
+    return make_double2(r1x + distance * sc.c, r1y + distance * sc.s);
+}
+
+// One wavefront per env whose episode has ended (front <= 5, not yet reset: step with auto_reset = 0).  Codes as
+// k_smooth_interior plus kSmoothNotFinished (front > 5: untouched) and kSmoothIndexError (the reference raises
+// IndexError at M:1311 / 1344 / 1348 on an empty common-neighbour list: untouched).
+__global__ void __launch_bounds__(64)
+k_smooth_final(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int iteration, double lr_1, double lr_2,
+               int32_t *__restrict__ sweeps_out, double *__restrict__ diff_out)
+{
+    extern __shared__ double2 smem[];
+    const int env = blockIdx.x, lane = lane_id();
+    if (mask && mask[env] == 0) {
+        if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothSkipped;
+        return;
+    }
+    const int log_cap = S.prm.log_cap;
+    const EnvScalars sc = S.scal[env];
+    const DevCold cold = load_cold(S);
+    const int n = uniform_i32(sc.n), n_elem = uniform_i32(sc.n_elem), n_new = uniform_i32(sc.n_new);
+    const int status = uniform_i32(sc.status);
+    if ((status & kStLogOverflow) || n_elem > log_cap || n_new > log_cap || n > 5) {
+        if (lane == 0 && sweeps_out) sweeps_out[env] = n > 5 ? kSmoothNotFinished : kSmoothLogOverflow;
+        return;
+    }
+    const DomConst dc = S.dom[uniform_i32(sc.dom)];
+    const int doff = uniform_i32(dc.off), n0 = uniform_i32(dc.n0), nv = n0 + n_new;
+    const size_t lbase = ((size_t)env * 2 + ((status >> 4) & 1)) * log_cap;
+    const int4 *quads = reinterpret_cast<const int4 *>(cold.log_quads + lbase * 4);
+    double2 *vnew = cold.log_vxy + lbase;
+
+    const int V = ring_cap + log_cap;
+    double2 *coord = smem;
+    unsigned short *adj = (unsigned short *)(coord + V);
+    unsigned short *ringu = adj + (size_t)V * kSmoothMaxDeg;     // the front as unified vertex indices
+    unsigned char *deg = (unsigned char *)(ringu + ring_cap);
+    unsigned char *n_mesh = deg + V;
+    unsigned char *front = n_mesh + V;
+
+    for (int i = lane; i < n0; i += 64) coord[i] = cold.dom_xy[doff + i];
+    for (int k = lane; k < n_new; k += 64) coord[n0 + k] = vnew[k];
+    for (int u = lane; u < nv; u += 64) front[u] = 0;
+    wave_sync();
+    const int32_t *rid = S.ring_id + (size_t)env * S.cap;
+    for (int i = lane; i < n; i += 64) {
+        const int g = rid[i];
+        const int u = (g & kNewBit) ? n0 + (g & ~kNewBit) : g;
+        ringu[i] = (unsigned short)u;
+        front[u] = 1;
+    }
+    const bool too_many = build_segment_lists(quads, n_elem, n0, 0, nv, adj, deg, n_mesh);
+    if (__ballot(too_many) != 0ULL) {
+        if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothDegree;
+        return;
+    }
+    wave_sync();
+    SmoothGraph g;
+    g.coord = coord; g.adj = adj; g.deg = deg;
+    // the stop rule's sum runs over the domain ring first: that prefix never changes
+    double sum_domain = 0.0;
+    for (int i0 = 0; i0 < n0; i0 += 64) {
+        const int i = i0 + lane;
+        double sv = 0.0;
+        if (i < n0) { const double2 c = coord[i]; sv = c.x + c.y; }
+        const int m = n0 - i0 < 64 ? n0 - i0 : 64;
+        for (int j = 0; j < m; j++) sum_domain += lane_f64(sv, j);
+    }
+    double sum_coordinates = 0.0, diffs = 100.0;
+    int it = 0;
+    bool index_error = false;
+    while (!index_error && diffs > 0.001 && it < iteration) {
+        it += 1;
+        for (int k = n0; k < nv && !index_error; k++) {
+            const int d = uniform_i32((int)deg[k]), nm = uniform_i32((int)n_mesh[k]);
+            const unsigned short *row = adj + (size_t)k * kSmoothMaxDeg;
+            bool pull = false;
+            if (nm == 1) {
+                if (d == 2) {
+                    const int c0 = uniform_i32((int)row[0]), c1 = uniform_i32((int)row[1]);
+                    const int origin = nearest_common(g, c0, c1, k, k);
+                    if (origin < 0) { index_error = true; break; }
+                    // compute_dist([front vertices that are neither neighbours of k nor k], origin)[0], M:1313-1318
+                    const double2 po = coord[origin];
+                    double bd = kInf;
+                    int bi = 0x7fffffff;
+                    for (int i = lane; i < n; i += 64) {
+                        const int w = ringu[i];
+                        if (w == c0 || w == c1 || w == k || w == origin) continue;
+                        const double2 pw = coord[w];
+                        const double dd = dist(mkp(po.x, po.y), mkp(pw.x, pw.y));
+                        if (dd < bd) { bd = dd; bi = i; }
+                    }
+                    const double dmin = wave_min_f64(bd);
+                    const int imin = -wave_max_i32(bd == dmin && bi != 0x7fffffff ? -bi : INT32_MIN + 1);
+                    if (imin != 0x7fffffff) {   // `if not len(p_dist): continue`
+                        const double2 nw = estimate_4th_vertex(po, coord[c0], coord[c1], 0.5, true, dmin);
+                        if (lane == 0) coord[k] = nw;
+                    }
+                } else {
+                    pull = true;
+                }
+            } else if (nm == 2) {
+                int ub0 = -1, ub1 = -1, in0 = -1, nu = 0, ni = 0;
+                for (int j = 0; j < d; j++) {
+                    const int w = uniform_i32((int)row[j]);
+                    if (uniform_i32((int)front[w]) != 0) { if (nu == 0) ub0 = w; else if (nu == 1) ub1 = w; nu += 1; }
+                    else { if (ni == 0) in0 = w; ni += 1; }
+                }
+                if (ni == 1 && nu == 2) {
+                    const int q1 = nearest_common(g, in0, ub0, k, k);
+                    const int q2 = nearest_common(g, in0, ub1, k, k);
+                    if (q1 < 0 || q2 < 0) { index_error = true; break; }
+                    const double2 e1 = estimate_4th_vertex(coord[q1], coord[ub0], coord[in0], 0.7, false, 0.0);
+                    const double2 e2 = estimate_4th_vertex(coord[q2], coord[ub1], coord[in0], 0.7, false, 0.0);
+                    if (lane == 0) coord[k] = make_double2((e1.x + e2.x) / 2, (e1.y + e2.y) / 2);
+                } else {
+                    pull = true;
+                }
+            } else if (d != 0) {
+                const double2 v = coord[k];
+                double tx = 0.0, ty = 0.0;
+                if (lane < d) {
+                    const double2 c = coord[row[lane]];
+                    tx = c.x + v.x;
+                    ty = c.y + v.y;
+                }
+                double x = 0.0 + lane_f64(tx, 0), y = 0.0 + lane_f64(ty, 0);   // the reference starts from an int 0
+                for (int j = 1; j < d; j++) {
+                    x += lane_f64(tx, j);
+                    y += lane_f64(ty, j);
+                }
+                if (lane == 0) coord[k] = make_double2(x / (double)(2 * d), y / (double)(2 * d));
+            }
+            if (pull) {
+                const double lr = nm == 1 ? lr_1 : lr_2;
+                double2 v = coord[k];
+                for (int j = 0; j < d; j++) {
+                    const double2 c = coord[uniform_i32((int)row[j])];
+                    v.x = lr * v.x + (1 - lr) * c.x;
+                    v.y = lr * v.y + (1 - lr) * c.y;
+                }
+                if (lane == 0) coord[k] = v;
+            }
+            wave_sync();
+        }
+        double new_sum = sum_domain;
+        for (int k0 = 0; k0 < n_new; k0 += 64) {
+            const int k = k0 + lane;
+            double sv = 0.0;
+            if (k < n_new) { const double2 c = coord[n0 + k]; sv = c.x + c.y; }
+            const int m = n_new - k0 < 64 ? n_new - k0 : 64;
+            for (int j = 0; j < m; j++) new_sum += lane_f64(sv, j);
+        }
+        diffs = fabs(new_sum - sum_coordinates);
+        sum_coordinates = new_sum;
+    }
+    if (index_error) {
+        if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothIndexError;
+        return;
+    }
+    for (int k = lane; k < n_new; k += 64) vnew[k] = coord[n0 + k];
+    // front vertices moved with the rest: the ring arrays hold copies of their coordinates
+    double2 *rxy = S.ring_xy + (size_t)env * S.cap;
+    for (int i = lane; i < n; i += 64) rxy[i] = coord[ringu[i]];
+    if (lane == 0) {
+        S.scal[env].status = status & ~(kStRm1Bad | kStRp1Bad);
         if (sweeps_out) sweeps_out[env] = it;
         if (diff_out) diff_out[env] = diffs;
     }

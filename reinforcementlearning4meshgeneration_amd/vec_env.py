@@ -296,6 +296,27 @@ class MeshVecEnv:
         self._check(rc, "meshenv_smooth")
         return self.smooth_sweeps, self.smooth_diff
 
+    def smooth(self, mask=None, lr_1: float = 0.999, lr_2: float = 0.999, iteration: int = 400):
+        """MeshGeneration.smooth(boundary.vertices, lr_1, lr_2, iteration) (general/mesh.py:1290-1392) on the FINISHED
+        running episodes (front <= 5, not reset yet: create the env with auto_reset=False): all generated vertices are
+        relaxed, front included.  Returns (sweeps int32 [n], diff float64 [n]); sweeps < 0: _capi.SMOOTH_* (env untouched,
+        e.g. SMOOTH_NOT_FINISHED for an episode that is still running)."""
+        t = self._torch
+        if not hasattr(self, "smooth_sweeps"):
+            self.smooth_sweeps = t.zeros(self.num_envs, dtype=t.int32, device=self.device)
+            self.smooth_diff = t.zeros(self.num_envs, dtype=t.float64, device=self.device)
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=t.uint8).contiguous()
+            if tuple(mask.shape) != (self.num_envs,):
+                raise ValueError(f"mask must have shape ({self.num_envs},)")
+            mptr = mask.data_ptr()
+        self._bind_stream()
+        rc = self._L.meshenv_smooth_final(self._handle, mptr, int(iteration), float(lr_1), float(lr_2),
+                                          self.smooth_sweeps.data_ptr(), self.smooth_diff.data_ptr())
+        self._check(rc, "meshenv_smooth_final")
+        return self.smooth_sweeps, self.smooth_diff
+
     def get_not_valid(self, env: int) -> np.ndarray:
         """not_valid_points of one env (rl/boundary_env.py:47): [k, 2] coordinates of the reference vertices whose
         moves were rejected since the last valid move / reset."""
