@@ -52,3 +52,49 @@ for k in range(0, shadow, 16):
     assert np.array_equal(env.get_elements(k)[1], refs[k].elements()[1])
 print(f"oracle (1 thread): {dt / shadow * 1e6:.1f} us/env -> {dt / shadow * n * 1e3:.1f} ms for {n} envs; device/oracle speed "
       f"{dt / shadow * n * 1e3 / ms:.0f}x; shadowed vertex tables bit-identical")
+
+# ---- finished meshes: meshenv_smooth_final (MeshGeneration.smooth), on the 13-vertex odd ring of the fixtures
+tr = np.load(os.path.join(ROOT, "tests", "golden", "smoothfinal_ring13_s4.npz"))
+dom = [tuple(p) for p in tr["domain_xy"]]
+nf = min(n, 32768)
+env = MeshVecEnv([dom], n_envs=nf, auto_reset=False, log_capacity=64)
+refs = [RefEnv.from_points(dom, cap_new=64) for _ in range(shadow)]
+batch = RefBatch(refs)
+env.reset(); batch.reset()
+finished = np.zeros(nf, bool)
+for t in range(200):
+    a = rng.uniform([-1, 0.2, 0.3], [1, 1.0, 1.2], size=(nf, 3)).astype(np.float32)
+    o, r, d, c = env.step(torch.from_numpy(a).cuda())
+    d = d.cpu().numpy().astype(bool); c = c.cpu().numpy().astype(bool)
+    batch.step(a[:shadow], auto_reset=False, threads=16)
+    trunc = ~finished & d & ~c
+    if trunc.any():
+        env.reset(mask=torch.from_numpy(trunc.astype(np.uint8)).cuda())
+        for k in np.nonzero(trunc[:shadow])[0]:
+            refs[k].reset()
+    finished |= d & c
+    if finished.mean() > 0.9:
+        break
+mask = torch.from_numpy(finished.astype(np.uint8)).cuda()
+env.smooth(mask=torch.zeros(nf, dtype=torch.uint8, device="cuda"))   # first-call set-up, nothing selected
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+sweeps, _ = env.smooth(mask=mask, iteration=400)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+sw = sweeps.cpu().numpy()
+nfin = int(finished.sum())
+st = [env.get_state(int(k)) for k in np.nonzero(finished)[0][:64]]
+print(f"finished meshes: {nfin} of {nf} envs ({np.mean([s['n_vert'] - s['n0'] for s in st]):.1f} generated vertices, "
+      f"{np.mean([s['n_elem'] for s in st]):.1f} elements each); device smooth(): {ms:.3f} ms ({ms * 1e3 / nfin:.3f} us/mesh), "
+      f"sweeps mean {sw[finished].mean():.1f} max {sw[finished].max()}")
+t0 = time.perf_counter()
+cnt = 0
+for k in np.nonzero(finished[:shadow])[0]:
+    s_ref = refs[k].smooth_final(400)[0]
+    assert s_ref == sw[k]
+    cnt += 1
+dt = time.perf_counter() - t0
+print(f"oracle (1 thread): {dt / max(cnt, 1) * 1e6:.1f} us/mesh -> {dt / max(cnt, 1) * nfin * 1e3:.1f} ms for {nfin}; "
+      f"device/oracle speed {dt / max(cnt, 1) * nfin * 1e3 / ms:.0f}x")
