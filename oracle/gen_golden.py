@@ -242,6 +242,25 @@ def main_final_smooth():
               f"branch visits {tr['call_branch'].sum(axis=0).tolist() if tr['n_calls'] else []}")
 
 
+# front smoothing: (fixture name, domain, seed, T, smooth after every k-th accepted element)
+FRONT_SMOOTH_TRACES = [
+    ("smoothfront_boundary0_s1", "boundary0", 1, 700, 3),
+    ("smoothfront_boundary0_s9", "boundary0", 9, 600, 2),
+    ("smoothfront_boundary16_s2", "boundary16", 2, 400, 3),
+    ("smoothfront_random1_1_s3", "random1_1", 3, 400, 2),
+    ("smoothfront_star_s5", "star", 5, 400, 2),
+]
+
+
+def main_front_smooth():
+    for name, dom, seed, T, every in FRONT_SMOOTH_TRACES:
+        tr = H.record_front_smooth_trace(H.domain_points(dom), H.biased_actions(seed, T), every)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **tr)
+        nc = int(tr["n_calls"])
+        print(f"{name}: {T} steps, {int(tr['valid'].sum())} valid, {nc} smooth_pave(interior=False) calls, "
+              f"{int(tr['call_raised'].sum()) if nc else 0} raised, {int(tr['call_obs_none'].sum()) if nc else 0} None")
+
+
 def main_move():
     for name, dom, seed, T, reset_on_done in MOVE_TRACES:
         pts = H.domain_points(dom) if isinstance(dom, str) else dom
@@ -257,6 +276,7 @@ def main():
     if "--smooth-only" in sys.argv:
         main_smooth()
         main_final_smooth()
+        main_front_smooth()
         return
     if "--quality-only" in sys.argv:
         quality_fixture()
@@ -275,6 +295,7 @@ def main():
     main_move()
     main_smooth()
     main_final_smooth()
+    main_front_smooth()
 
 
 if __name__ == "__main__":

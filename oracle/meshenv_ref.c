@@ -1148,6 +1148,300 @@ int meshenv_ref_smooth_final(RefEnv *e, int iteration, double lr_1, double lr_2,
     return 0;
 }
 
+/* ------------------------------------------------- the front smoother: smooth_current_boundary_3, M:939-1028
+ *
+ * smooth_pave(..., interior=False) (M:790-795) runs it before smooth_fixed_vertices; move() enters smooth_pave when no
+ * reference vertex is selectable (B:405-412).  Every generated vertex ON the front, in ring order and in place, by its
+ * interior angle: <= 90 -> middle_vertex on the bisector for a target angle raised in steps of 5 until the new position
+ * keeps every surrounding element on its side (is_inside_boundary over clockwise_vertices); (90, 180] -> side_vertex
+ * next to a sharp (< 45) neighbour corner, else find_indention_vertex; (180, 270] -> find_indention_vertex; beyond ->
+ * inner_vertex then find_indention_vertex.  Returns 0, -1 (log / degree overflow), -3 where the reference raises
+ * (ValueError from math.sqrt of a negative number, ZeroDivisionError): the vertices moved before that stay moved, as in
+ * the reference. */
+typedef struct {
+    RefEnv *e;
+    Graph g;
+    int raised;
+} Front;
+
+static double py_sqrt(Front *f, double v)
+{
+    if (v < 0) { f->raised = 1; return 0.0; } /* ValueError: math domain error */
+    return sqrt(v);
+}
+
+static double py_div(Front *f, double a, double b)
+{
+    if (b == 0) { f->raised = 1; return 0.0; } /* ZeroDivisionError */
+    return a / b;
+}
+
+static double deg2rad(double a) { return a * (PI / 180.0); } /* math.radians */
+static double rad2deg(double a) { return a * (180.0 / PI); } /* math.degrees */
+
+/* the two intersections of the circle |p - (a, b)| = dist with the line A x + B y = W + A a + B b, M:841-858 / 889-904 */
+static void circle_line(Front *f, double a, double b, double A, double B, double W, double dist, P2 *v1, P2 *v2)
+{
+    if (B == 0) {
+        double wa = py_div(f, W, A);
+        double r = py_sqrt(f, SQ(dist) - SQ(wa));
+        v1->x = wa + a; v2->x = wa + a;
+        v1->y = b + r; v2->y = b - r;
+    } else if (A == 0) {
+        double wb = W / B;
+        double r = py_sqrt(f, SQ(dist) - SQ(wb));
+        v1->x = a + r; v2->x = a - r;
+        v1->y = wb + b; v2->y = wb + b;
+    } else {
+        double M = -A / B;
+        double N = (W + A * a + B * b) / B;
+        double t = 2 * M * b - 2 * M * N + 2 * a;
+        double disc = fabs(SQ(t) - 4 * (SQ(M) + 1) * (SQ(N - b) + SQ(a) - SQ(dist)));
+        double den = 2 * (SQ(M) + 1);
+        v1->x = (t + sqrt(disc)) / den;
+        v2->x = (t - sqrt(disc)) / den;
+        v1->y = M * v1->x + N;
+        v2->y = M * v2->x + N;
+    }
+}
+
+/* M:805-832 */
+static P2 middle_vertex(Front *f, P2 vertex, P2 left, P2 right, double target_angle)
+{
+    P2 m = {(left.x + right.x) / 2, (left.y + right.y) / 2};
+    double A = right.x - left.x, B = right.y - left.y;
+    double D = dist(left, m) / tan(deg2rad(target_angle / 2));
+    P2 v1, v2;
+    if (B == 0) {
+        v1.x = m.x; v2.x = m.x; v1.y = m.y + D; v2.y = m.y - D;
+    } else if (A == 0) {
+        v1.x = m.x + D; v2.x = m.x - D; v1.y = m.y; v2.y = m.y;
+    } else {
+        double M = -A / B;
+        double N = A * m.x / B + m.y;
+        double t = -2 * M * N + 2 * m.x + 2 * M * m.y;
+        double disc = fabs(SQ(t) - 4 * (SQ(M) + 1) * (SQ(N - m.y) + SQ(m.x) - SQ(D)));
+        double den = 2 * (SQ(M) + 1);
+        v1.x = (t + sqrt(disc)) / den;
+        v2.x = (t - sqrt(disc)) / den;
+        v1.y = M * v1.x + N;
+        v2.y = M * v2.x + N;
+    }
+    (void)f;
+    return dist(v1, vertex) < dist(v2, vertex) ? v1 : v2;
+}
+
+/* M:834-863 */
+static P2 side_vertex(Front *f, P2 vertex, P2 next_v, P2 nn_v, double angle, double d)
+{
+    double W = d * dist(next_v, nn_v) * cos(deg2rad(angle));
+    P2 v1, v2;
+    circle_line(f, next_v.x, next_v.y, nn_v.x - next_v.x, nn_v.y - next_v.y, W, d, &v1, &v2);
+    return dist(v1, vertex) < dist(v2, vertex) ? v1 : v2;
+}
+
+/* M:882-909 */
+static P2 indention_vertex(Front *f, P2 vertex, P2 left, P2 right, double angle, double d)
+{
+    double W = d * dist(vertex, left) * cos(deg2rad(angle));
+    P2 v1, v2;
+    circle_line(f, vertex.x, vertex.y, left.x - vertex.x, left.y - vertex.y, W, d, &v1, &v2);
+    return cw(v1, left, right) < cw(v2, left, right) ? v1 : v2;
+}
+
+/* clockwise_vertices, M:1080-1101: the neighbours of `inner` sorted by clockwise angle (selection sort as written), each
+ * followed by the common neighbour it shares with its successor.  out: vertex ids; returns the length. */
+static int clockwise_vertices(Front *f, int inner, int *out)
+{
+    const RefEnv *e = f->e;
+    const Graph *g = &f->g;
+    int vs[MESHENV_REF_MAX_DEG];
+    const int n = g->deg[inner];
+    for (int j = 0; j < n; j++) vs[j] = g->adj[inner * MESHENV_REF_MAX_DEG + j];
+    for (int i = 1; i < n; i++) {
+        double max_angle = -1;
+        int flag = i;
+        for (int j = i; j < n; j++) {
+            double a = cw(e->vtab[inner], e->vtab[vs[j]], e->vtab[vs[i - 1]]);
+            if (a > max_angle) { max_angle = a; flag = j; }
+        }
+        if (flag != i) { int t = vs[i]; vs[i] = vs[flag]; vs[flag] = t; }
+    }
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const int cur = vs[i], prev = vs[(i + n - 1) % n];
+        int inter = -1;
+        for (int j = 0; j < g->deg[cur] && inter < 0; j++) {
+            int w = g->adj[cur * MESHENV_REF_MAX_DEG + j];
+            if (w != inner && graph_has(g, prev, w)) inter = w;
+        }
+        out[m++] = prev;
+        if (inter >= 0) out[m++] = inter;
+    }
+    return m;
+}
+
+/* is_inside_boundary, M:1069-1078 */
+static int is_inside_boundary(const RefEnv *e, P2 original, P2 moved, const int *b, int nb, int left, int right)
+{
+    for (int i = 0; i < nb; i++) {
+        const int bi = b[i], bp = b[(i + nb - 1) % nb];
+        if ((left == bi || left == bp) && (right == bi || right == bp)) continue;
+        if ((cw(moved, e->vtab[bi], e->vtab[bp]) < PI) != (cw(original, e->vtab[bi], e->vtab[bp]) < PI)) return 0;
+    }
+    return 1;
+}
+
+/* M:911-937; ids: vertex, _next_v, next_v, nn_v */
+static P2 find_side_vertex(Front *f, int v, int _next, int next, int nn, double v_angle)
+{
+    const RefEnv *e = f->e;
+    const P2 pv = e->vtab[v];
+    const double d = (dist(pv, e->vtab[_next]) + dist(pv, e->vtab[next]) + dist(e->vtab[next], e->vtab[nn])) / 3;
+    double target = 45;
+    for (;;) {
+        P2 nv = side_vertex(f, pv, e->vtab[next], e->vtab[nn], target, d);
+        if (f->raised) return pv;
+        if (target <= v_angle) return pv;
+        int cb[2 * MESHENV_REF_MAX_DEG];
+        int nb = clockwise_vertices(f, v, cb);
+        if (is_inside_boundary(e, pv, nv, cb, nb, _next, next)) return nv;
+        target -= 5;
+    }
+}
+
+/* M:1030-1067; index = ring slot of the vertex */
+static P2 find_indention_vertex(Front *f, int index, double v_angle)
+{
+    RefEnv *e = f->e;
+    const int n = e->n;
+    const int v = e->rid[index], left = e->rid[(index + 1) % n], right = e->rid[RI(index - 1, n)];
+    const int l2 = e->rid[(index + 2) % n], r2 = e->rid[RI(index - 2, n)];
+    const P2 pv = e->vtab[v];
+    const double d = (dist(pv, e->vtab[left]) + dist(pv, e->vtab[right])) / 2;
+    int near = 0;
+    /* Boundary2D.get_closet_points(front, vertex, [r2, right, left, l2], d): any other front vertex within d */
+    for (int i = 0; i < n && !near; i++) {
+        int w = e->rid[i];
+        if (w == v || w == r2 || w == right || w == left || w == l2) continue;
+        if (dist(pv, e->vtab[w]) <= d) near = 1;
+    }
+    /* find_closest_segments, M:1103-1112: a front segment (not at the vertex) whose foot point lies inside it, within d */
+    for (int i = 0; i < n && !near; i++) {
+        int p1 = e->rid[RI(i - 1, n)], p2 = e->rid[i];
+        if (p1 == v || p2 == v) continue;
+        const P2 a = e->vtab[p1], b = e->vtab[p2];
+        double A = b.x - a.x, B = b.y - a.y;
+        double s = py_div(f, A * pv.x + B * pv.y - B * a.y - A * a.x, SQ(A) + SQ(B));
+        if (f->raised) return pv;
+        P2 t = {a.x + s * A, a.y + s * B};
+        if (0 <= s && s <= 1 && dist(pv, t) <= d) near = 1;
+    }
+    if (!near) return pv;
+    int times = 4;
+    for (;;) {
+        P2 nv = indention_vertex(f, pv, e->vtab[left], e->vtab[right], (360 - v_angle) / 2, d / times);
+        if (f->raised) return pv;
+        if (times >= 10) return pv;
+        int cb[2 * MESHENV_REF_MAX_DEG];
+        int nb = clockwise_vertices(f, v, cb);
+        if (is_inside_boundary(e, pv, nv, cb, nb, left, right)) return nv;
+        times += 1;
+    }
+}
+
+static int build_full_graph(const RefEnv *e, Graph *g)
+{
+    const int nv = e->n_vert, n0 = e->n0;
+    int rc = 0;
+    g->adj = (int32_t *)malloc(sizeof(int32_t) * (size_t)nv * MESHENV_REF_MAX_DEG);
+    g->deg = (int32_t *)calloc((size_t)nv, sizeof(int32_t));
+    for (int i = 0; i < n0 && rc == 0; i++) {
+        int a = (i + n0 - 1) % n0;
+        rc |= graph_add(g, a, i);
+        rc |= graph_add(g, i, a);
+    }
+    for (int k = 0; k < e->n_elem && rc == 0; k++) {
+        const int32_t *q = e->quads + 4 * k;
+        for (int i = 0; i < 4 && rc == 0; i++) {
+            const int a = q[i], b = q[(i + 3) & 3];
+            if (graph_has(g, a, b)) continue;
+            rc |= graph_add(g, a, b);
+            rc |= graph_add(g, b, a);
+        }
+    }
+    return rc;
+}
+
+int meshenv_ref_smooth_front(RefEnv *e)
+{
+    if (e->n_elem > e->cap_e || e->n_vert > e->cap_v) return -1;
+    Front f;
+    f.e = e;
+    f.raised = 0;
+    if (build_full_graph(e, &f.g) != 0) { free(f.g.adj); free(f.g.deg); return -1; }
+    const int n = e->n;
+    for (int i = 0; i < n && !f.raised; i++) {
+        const int v = e->rid[i];
+        if (v < e->n0) continue;
+        const int nxt = e->rid[(i + 1) % n], prv = e->rid[RI(i - 1, n)];
+        const double v_angle = rad2deg(cw(e->vtab[v], e->vtab[nxt], e->vtab[prv]));
+        P2 nv = e->vtab[v];
+        if (v_angle <= 90) {
+            double target = v_angle >= 45 ? v_angle : 45;
+            for (;;) {
+                P2 cand = middle_vertex(&f, e->vtab[v], e->vtab[nxt], e->vtab[prv], target);
+                if (target >= 135) break;
+                int cb[2 * MESHENV_REF_MAX_DEG];
+                int nb = clockwise_vertices(&f, v, cb);
+                if (is_inside_boundary(e, e->vtab[v], cand, cb, nb, nxt, prv)) { nv = cand; break; }
+                target += 5;
+            }
+        } else if (v_angle <= 180) {
+            const int nn_r = e->rid[RI(i - 2, n)], nn_l = e->rid[(i + 2) % n];
+            /* compute_boundary_angle, C:467-473 */
+            const double left_angle = rad2deg(cw(e->vtab[nxt], e->vtab[nn_l], e->vtab[v]));
+            const double right_angle = rad2deg(cw(e->vtab[prv], e->vtab[v], e->vtab[nn_r]));
+            if (right_angle < 45) nv = find_side_vertex(&f, v, nxt, prv, nn_r, right_angle);
+            else if (left_angle < 45) nv = find_side_vertex(&f, v, prv, nxt, nn_l, left_angle);
+            else nv = find_indention_vertex(&f, i, v_angle);
+        } else if (v_angle <= 270) {
+            nv = find_indention_vertex(&f, i, v_angle);
+        } else {
+            /* inner_vertex(vertex, 45), M:865-880 */
+            const P2 l = e->vtab[nxt], r = e->vtab[prv], pv = e->vtab[v];
+            P2 m = {(l.x + r.x) / 2, (l.y + r.y) / 2};
+            double d = dist(m, r) * tan(deg2rad(45));
+            double A = pv.x - m.x, B = pv.y - m.y;
+            double q = py_div(&f, SQ(d), SQ(A) + SQ(B));
+            if (f.raised) break;
+            double sc = sqrt(q);
+            e->vtab[v].x = m.x + sc * A;
+            e->vtab[v].y = m.y + sc * B;
+            e->ring[i] = e->vtab[v];
+            nv = find_indention_vertex(&f, i, v_angle);
+        }
+        if (f.raised) break;
+        e->vtab[v] = nv;
+        e->ring[i] = nv;
+    }
+    free(f.g.adj); free(f.g.deg);
+    return f.raised ? -3 : 0;
+}
+
+/* smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=..., interior=False), M:790-795, followed by the
+ * find_next_state that move() runs right after it (B:420; is_static selects its observation form): front smoother,
+ * interior relaxation, candidate list rebuilt, reference vertex and observation of the smoothed state.  Returns the
+ * "observation is None" flag (>= 0), or the negative codes of the parts. */
+int meshenv_ref_smooth_pave_full(RefEnv *e, int iteration, int is_static, float *obs, int32_t *sweeps_out)
+{
+    int rc = meshenv_ref_smooth_front(e);
+    if (rc != 0) return rc;
+    rc = meshenv_ref_smooth_interior(e, iteration, sweeps_out, NULL);
+    if (rc != 0) return rc;
+    return find_next_state_opt(e, obs, is_static, 0);
+}
+
 int meshenv_ref_not_valid_count(const RefEnv *e) { return e->n_nv; }
 
 int meshenv_ref_ring_len(const RefEnv *e) { return e->n; }

@@ -443,3 +443,104 @@ def record_final_smooth_trace(points, actions: np.ndarray, iteration: int = 400,
             out["call_quads"][k, :len(c["quads"])] = c["quads"]
             out["call_ring"][k, :len(c["ring"])] = c["ring"]
     return out
+
+
+def record_front_smooth_trace(points, actions: np.ndarray, smooth_every: int, iteration: int = 400) -> dict:
+    """As record_smooth_trace, but the call is smooth_pave(..., interior=False) -- smooth_current_boundary_3 on the front
+    (general/mesh.py:939-1028), then the interior relaxation and the candidate rebuild -- followed by the
+    find_next_state() that move() runs right after it (rl/boundary_env.py:405-420), whose observation is recorded.  A
+    call in which the reference raises (math domain error / division by zero inside the vertex constructions) is
+    recorded with raised = 1 and the partly smoothed vertex table; the episode is reset after it."""
+    import contextlib
+    import io
+    import re
+    env = make_env(points)
+    T = len(actions)
+    reset_obs = env.reset()
+
+    def ids_of(vlist):
+        table = {id(v): k for k, v in enumerate(env.boundary.vertices)}
+        return [table[id(v)] for v in vlist]
+
+    out = dict(
+        obs=np.zeros((T, 18), np.float32), obs_none=np.zeros(T, np.uint8), reward=np.zeros(T, np.float64),
+        done=np.zeros(T, np.uint8), complete=np.zeros(T, np.uint8), ring_len=np.zeros(T, np.int32),
+        n_elem=np.zeros(T, np.int32), valid=np.zeros(T, np.uint8),
+    )
+    calls = []
+    since = 0
+    for t in range(T):
+        nelem_before = len(env.generated_meshes)
+        obs, rew, done, info = env.step(actions[t])
+        out["obs_none"][t] = obs is None
+        if obs is not None:
+            out["obs"][t] = obs
+        out["reward"][t] = rew
+        out["done"][t] = done
+        out["complete"][t] = info["is_complete"]
+        out["ring_len"][t] = len(env.updated_boundary.vertices)
+        out["n_elem"][t] = len(env.generated_meshes)
+        valid = len(env.generated_meshes) > nelem_before
+        out["valid"][t] = valid
+        since += int(valid)
+        if done:
+            env.reset()
+            since = 0
+        elif valid and since >= smooth_every:
+            since = 0
+            before = np.array([(v.x, v.y) for v in env.boundary.vertices], np.float64)
+            quads = np.array([ids_of(m.vertices) for m in env.generated_meshes], np.int32)
+            ring = np.array(ids_of(env.updated_boundary.vertices), np.int32)
+            buf = io.StringIO()
+            raised, sweeps, s_obs, s_none = 0, -1, np.zeros(18, np.float32), 0
+            try:
+                with contextlib.redirect_stdout(buf):
+                    env.smooth_pave(env.boundary.vertices, env.updated_boundary.vertices, iteration=iteration, interior=False)
+                m = re.search(r"Iteration numbers: (\d+), the diff of smoothing is ([-+0-9.e]+)!", buf.getvalue())
+                sweeps = int(m.group(1))
+                o2 = env.find_next_state(env.not_valid_points)
+                s_none = o2 is None
+                if o2 is not None:
+                    s_obs = np.asarray(o2, np.float32)
+            except (ValueError, ZeroDivisionError):
+                raised = 1
+            after = np.array([(v.x, v.y) for v in env.boundary.vertices], np.float64)
+            cv = env.candidate_vertices
+            calls.append(dict(t=t, before=before, after=after, quads=quads, ring=ring, sweeps=sweeps, raised=raised,
+                              obs=s_obs, obs_none=s_none,
+                              ref=-1 if (raised or s_none) else ids_of([env.current_point_environment.reference_point])[0],
+                              cand_ids=np.array(ids_of([c[0] for c in cv]), np.int32),
+                              cand_keys=np.array([float(c[1]) for c in cv], np.float64)))
+            if raised:
+                env.reset()
+    out.update(domain_xy=np.array(points, np.float64), actions=actions, reset_obs=reset_obs.astype(np.float32),
+               consts=np.array([float(env.original_area), float(env.average_edge_length),
+                                float(env.estimated_area_range[0]), float(env.estimated_area_range[1])], np.float64),
+               n_calls=np.int32(len(calls)), iteration=np.int32(iteration))
+    if calls:
+        V = max(len(c["before"]) for c in calls)
+        E = max(len(c["quads"]) for c in calls)
+        R = max(len(c["ring"]) for c in calls)
+        K = max(len(c["cand_ids"]) for c in calls)
+        nC = len(calls)
+        out.update(
+            call_t=np.array([c["t"] for c in calls], np.int32), call_sweeps=np.array([c["sweeps"] for c in calls], np.int32),
+            call_raised=np.array([c["raised"] for c in calls], np.uint8),
+            call_obs=np.stack([c["obs"] for c in calls]), call_obs_none=np.array([c["obs_none"] for c in calls], np.uint8),
+            call_ref=np.array([c["ref"] for c in calls], np.int32),
+            call_nv=np.array([len(c["before"]) for c in calls], np.int32),
+            call_ne=np.array([len(c["quads"]) for c in calls], np.int32),
+            call_nr=np.array([len(c["ring"]) for c in calls], np.int32),
+            call_nc=np.array([len(c["cand_ids"]) for c in calls], np.int32),
+            call_before=np.full((nC, V, 2), np.nan), call_after=np.full((nC, V, 2), np.nan),
+            call_quads=np.full((nC, E, 4), -1, np.int32), call_ring=np.full((nC, R), -1, np.int32),
+            call_cand_ids=np.full((nC, K), -1, np.int32), call_cand_keys=np.full((nC, K), np.nan),
+        )
+        for k, c in enumerate(calls):
+            out["call_before"][k, :len(c["before"])] = c["before"]
+            out["call_after"][k, :len(c["after"])] = c["after"]
+            out["call_quads"][k, :len(c["quads"])] = c["quads"]
+            out["call_ring"][k, :len(c["ring"])] = c["ring"]
+            out["call_cand_ids"][k, :len(c["cand_ids"])] = c["cand_ids"]
+            out["call_cand_keys"][k, :len(c["cand_keys"])] = c["cand_keys"]
+    return out

@@ -47,6 +47,10 @@ def lib():
     L.meshenv_ref_smooth_final.restype = C.c_int
     L.meshenv_ref_smooth_final.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, _i32p, _f64p,
                                            np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
+    L.meshenv_ref_smooth_front.restype = C.c_int
+    L.meshenv_ref_smooth_front.argtypes = [C.c_void_p]
+    L.meshenv_ref_smooth_pave_full.restype = C.c_int
+    L.meshenv_ref_smooth_pave_full.argtypes = [C.c_void_p, C.c_int, C.c_int, _f32p, _i32p]
     L.meshenv_ref_not_valid_count.restype = C.c_int
     L.meshenv_ref_not_valid_count.argtypes = [C.c_void_p]
     L.meshenv_ref_step.restype = C.c_int
@@ -159,6 +163,14 @@ class RefEnv:
         if rc != 0:
             raise RuntimeError(f"meshenv_ref_smooth_final: code {rc} (-1 log / degree overflow, -2 the reference raises IndexError)")
         return int(sw[0]), float(df[0]), br
+
+    def smooth_pave_full(self, iteration=400, static=False):
+        """smooth_pave(..., interior=False) + find_next_state(static=static) -> (code, sweeps, obs): code 0 / 1 = the
+        observation is an array / None, -3 = the reference raises inside the front smoother (front partly smoothed),
+        -1 = log overflow."""
+        sw = np.zeros(1, np.int32)
+        code = self.L.meshenv_ref_smooth_pave_full(self.h, int(iteration), int(bool(static)), self._obs, sw)
+        return int(code), int(sw[0]), self._obs.copy()
 
     def not_valid_count(self):
         return int(self.L.meshenv_ref_not_valid_count(self.h))

@@ -30,6 +30,11 @@ def smooth_golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("smooth_"))
 
 
+def front_smooth_golden_names():
+    """Recorded smooth_pave(interior=False) + find_next_state calls of the reference (oracle/gen_golden.py --smooth-only)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("smoothfront_"))
+
+
 def final_smooth_golden_names():
     """Recorded smooth() calls of the reference on finished meshes (oracle/gen_golden.py --smooth-only)."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("smoothfinal_"))

@@ -72,3 +72,48 @@ def replay_final(tr, impl, vertex_tol=0.0):
         if d:
             impl.reset()
     return worst
+
+
+def replay_front(tr, impl, obs_tol=0.0, vertex_tol=0.0, key_tol=0.0):
+    """smoothfront_*.npz: step() with smooth_pave(interior=False) + find_next_state calls in between.
+    impl.smooth_full(iteration) -> (code, sweeps, obs): code 0 / 1 observation array / None, -3 the reference raises."""
+    calls = {int(t): k for k, t in enumerate(tr["call_t"])}
+    iteration = int(tr["iteration"])
+    o = impl.reset()
+    assert np.abs(o.astype(np.float64) - tr["reset_obs"]).max() <= obs_tol
+    worst = 0.0
+    front_moves = 0
+    for t in range(len(tr["actions"])):
+        o, r, d, c = impl.step(tr["actions"][t])
+        assert bool(d) == bool(tr["done"][t]) and bool(c) == bool(tr["complete"][t]), t
+        if not tr["obs_none"][t]:
+            assert np.abs(np.asarray(o, np.float64) - tr["obs"][t]).max() <= obs_tol, t
+        assert abs(r - tr["reward"][t]) <= max(obs_tol, 1e-12), t
+        if d:
+            impl.reset()
+        if t in calls:
+            k = calls[t]
+            nv, ne, nr, nc = (int(tr[x][k]) for x in ("call_nv", "call_ne", "call_nr", "call_nc"))
+            assert np.array_equal(impl.elements(), tr["call_quads"][k, :ne]), t
+            assert np.array_equal(impl.ring_ids(), tr["call_ring"][k, :nr]), t
+            assert np.abs(impl.vertices() - tr["call_before"][k, :nv]).max() <= vertex_tol, t
+            code, sweeps, obs = impl.smooth_full(iteration)
+            want = tr["call_after"][k, :nv]
+            dev = float(np.abs(impl.vertices() - want).max())
+            assert dev <= vertex_tol, (t, dev)
+            worst = max(worst, dev)
+            ring = tr["call_ring"][k, :nr]
+            front_moves += int(np.any(want[ring] != tr["call_before"][k, :nv][ring], axis=1).sum())
+            if tr["call_raised"][k]:
+                assert code == -3, (t, code)
+                impl.reset()
+                continue
+            assert code == int(tr["call_obs_none"][k]), (t, code)
+            assert sweeps == int(tr["call_sweeps"][k]), (t, sweeps, int(tr["call_sweeps"][k]))
+            if not tr["call_obs_none"][k]:
+                assert np.abs(np.asarray(obs, np.float64) - tr["call_obs"][k]).max() <= obs_tol, t
+                assert impl.ref_id() == int(tr["call_ref"][k]), t
+            ids, keys = impl.candidates()
+            assert np.array_equal(ids, tr["call_cand_ids"][k, :nc]), t
+            assert np.abs(keys - tr["call_cand_keys"][k, :nc]).max(initial=0.0) <= key_tol, t
+    return worst, front_moves

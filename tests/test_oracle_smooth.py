@@ -6,8 +6,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_DIR, final_smooth_golden_names, smooth_golden_names
-from smooth_replay import replay, replay_final
+from conftest import GOLDEN_DIR, final_smooth_golden_names, front_smooth_golden_names, smooth_golden_names
+from smooth_replay import replay, replay_final, replay_front
 
 
 class OracleImpl:
@@ -25,6 +25,12 @@ class OracleImpl:
 
     def smooth(self, iteration):
         return self.env.smooth_interior(iteration)[0]
+
+    def smooth_full(self, iteration):
+        return self.env.smooth_pave_full(iteration)
+
+    def ref_id(self):
+        return self.env.ref_id()
 
     def smooth_final(self, iteration):
         return self.env.smooth_final(iteration)[0]
@@ -73,3 +79,13 @@ def test_final_smooth_fixtures_cover_all_three_branches_and_both_front_sizes():
     fronts = np.concatenate([t["call_nr"] for t in trs])
     assert (fronts == 4).any() and (fronts == 5).any()
     assert any((t["call_sweeps"] == int(t["iteration"])).any() for t in trs)
+
+
+@pytest.mark.parametrize("name", front_smooth_golden_names())
+def test_oracle_front_smoother_matches_reference_records(name):
+    """smooth_pave(..., interior=False) -- smooth_current_boundary_3 (general/mesh.py:939-1028) + the interior relaxation +
+    the rebuild -- and the find_next_state after it: vertex table, sweeps, observation, reference vertex, candidate list
+    and every later step() as the reference recorded them."""
+    tr = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    worst, front_moves = replay_front(tr, OracleImpl(tr))
+    assert int(tr["n_calls"]) >= 5 and front_moves > 0
