@@ -206,25 +206,38 @@ enum {
 int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, float *obs_dev, uint8_t *done_dev,
                  uint8_t *complete_dev, uint8_t *code_dev);
 
-/* MeshGeneration.smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=..., interior=True),
- * general/mesh.py:790-795 (the post-processing call of general/EBRD.py:393), on the RUNNING episode of every env with
- * mask_dev[e] != 0 (mask_dev NULL: all): smooth_fixed_vertices (general/mesh.py:1258-1288) -- Gauss-Seidel relaxation of
- * the generated vertices that are off the front, in boundary.vertices order, until the moved vertices' coordinate sum
- * changes by <= 0.001 or `iteration` sweeps -- then find_reference_candidates(0) (general/mesh.py:233-261) on the front.
- * The Vertex.segments graph the reference walks is rebuilt from the element log, so the handle needs log_capacity > 0.
- * The vertex log (meshenv_get_elements, meshenv_element_quality) holds the moved coordinates afterwards; the front, the
- * reference vertex and the observation are unchanged (as in the reference), the candidate list is the rebuilt one.
- *   sweeps_dev [n_envs] int32, nullable: sweeps made; MESHENV_SMOOTH_SKIPPED for masked-out envs,
+/* MeshGeneration.smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=..., interior=...),
+ * general/mesh.py:790-795, on the RUNNING episode of every env with mask_dev[e] != 0 (mask_dev NULL: all).  The
+ * Vertex.segments graph the reference walks is rebuilt from the element log, so the handle needs log_capacity > 0.
+ *
+ * interior != 0 (the post-processing call of general/EBRD.py:393): smooth_fixed_vertices (general/mesh.py:1258-1288) --
+ *   Gauss-Seidel relaxation of the generated vertices that are off the front, in boundary.vertices order, until the moved
+ *   vertices' coordinate sum changes by <= 0.001 or `iteration` sweeps -- then find_reference_candidates(0)
+ *   (general/mesh.py:233-261) on the front.  The front, the reference vertex and the observation are unchanged (as in the
+ *   reference), the candidate list is the rebuilt one; the first step after the call must be a meshenv_step (it commits
+ *   the re-selection the rebuild parked: the reference re-selects at the end of every step, accepted or not).
+ *   is_static and obs_dev are ignored.
+ * interior == 0 (what move() runs when no reference vertex is selectable, rl/boundary_env.py:405-420):
+ *   smooth_current_boundary_3 (general/mesh.py:939-1028) moves the generated vertices ON the front first, then the two
+ *   steps above; because the front moved, the point environment is recomputed at once -- find_next_state(static =
+ *   is_static != 0), the call move() makes right after smooth_pave -- and obs_dev [n_envs][18] (nullable) receives its
+ *   observation (zeros where the reference returns None: status bit MESHENV_ST_NO_REFERENCE).
+ *
+ * The vertex log (meshenv_get_elements, meshenv_element_quality) holds the moved coordinates afterwards.
+ *   sweeps_dev [n_envs] int32, nullable: sweeps of the interior relaxation; MESHENV_SMOOTH_SKIPPED for masked-out envs;
  *              MESHENV_SMOOTH_LOG_OVERFLOW (status bit MESHENV_ST_LOG_OVERFLOW: graph incomplete) and
- *              MESHENV_SMOOTH_DEGREE (a vertex with more than 16 neighbours) leave the env untouched
- *   diff_dev   [n_envs] float64, nullable: the last |sum - previous sum| (what the reference prints)
- * interior = 0 (smooth_current_boundary_3 on the front itself, general/mesh.py:939-1028) is not built: MESHENV_E_ARG. */
+ *              MESHENV_SMOOTH_DEGREE (a vertex with more than 16 neighbours) leave the env untouched;
+ *              MESHENV_SMOOTH_RAISES: the reference raises inside the front smoother (math domain error / division by
+ *              zero in a vertex construction) -- the vertices moved before that point stay moved, nothing else ran
+ *   diff_dev   [n_envs] float64, nullable: the last |sum - previous sum| (what the reference prints) */
 enum {
     MESHENV_SMOOTH_SKIPPED = -1, MESHENV_SMOOTH_LOG_OVERFLOW = -2, MESHENV_SMOOTH_DEGREE = -3,
     MESHENV_SMOOTH_NOT_FINISHED = -4, /* meshenv_smooth_final on a front of more than 5 vertices */
-    MESHENV_SMOOTH_INDEX_ERROR = -5   /* the reference raises IndexError here (empty common-neighbour list) */
+    MESHENV_SMOOTH_INDEX_ERROR = -5,  /* the reference raises IndexError here (empty common-neighbour list) */
+    MESHENV_SMOOTH_RAISES = -6
 };
-int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int interior, int32_t *sweeps_dev, double *diff_dev);
+int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int interior, int is_static, int32_t *sweeps_dev,
+                   double *diff_dev, float *obs_dev);
 
 /* MeshGeneration.smooth(boundary.vertices, lr_1, lr_2, iteration), general/mesh.py:1290-1392 -- the post-processing of a
  * FINISHED mesh (general/EBRD.py:391: front of <= 5 vertices) -- on every env with mask_dev[e] != 0 whose running episode

@@ -13,7 +13,7 @@ ACT_DIM = 3
 ST_NO_REFERENCE = 1
 ST_LOG_OVERFLOW = 2
 MOVE_OK, MOVE_NONE, MOVE_RAISES, MOVE_NEEDS_SMOOTHING = 0, 1, 2, 3
-SMOOTH_SKIPPED, SMOOTH_LOG_OVERFLOW, SMOOTH_DEGREE, SMOOTH_NOT_FINISHED, SMOOTH_INDEX_ERROR = -1, -2, -3, -4, -5
+SMOOTH_SKIPPED, SMOOTH_LOG_OVERFLOW, SMOOTH_DEGREE, SMOOTH_NOT_FINISHED, SMOOTH_INDEX_ERROR, SMOOTH_RAISES = -1, -2, -3, -4, -5, -6
 
 
 class MeshEnvParams(C.Structure):
@@ -97,7 +97,7 @@ def load():
     L.meshenv_reset_static.argtypes = [vp, u8p, f32p, C.c_int]
     L.meshenv_move.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.meshenv_get_not_valid.argtypes = [vp, C.c_int, vp, C.c_int, i32p]
-    L.meshenv_smooth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    L.meshenv_smooth.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.meshenv_smooth.restype = C.c_int
     L.meshenv_smooth_final.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, vp, vp]
     L.meshenv_smooth_final.restype = C.c_int

@@ -98,10 +98,21 @@ class BoudaryEnv:  # the reference's spelling
         """MeshGeneration.smooth_pave, general/mesh.py:790-795.  The two vertex lists of the reference's signature are
         implied here (boundary.vertices and the current front of this env) and ignored; lr_1 / lr_2 are unused by the
         reference as well.  interior=True (the call general/EBRD.py:393 makes): the generated vertices off the front are
-        relaxed and the candidate list is rebuilt; returns the number of sweeps (the reference prints it).
-        interior=False would first run smooth_current_boundary_3 on the front: not built, NotImplementedError."""
+        relaxed and the candidate list is rebuilt.  interior=False: smooth_current_boundary_3 moves the front's generated
+        vertices first; since the front moved, the point environment is recomputed right away (the find_next_state that
+        move() runs after smooth_pave) and `current_state` holds its observation.  Returns the number of sweeps (the
+        reference prints it); raises ValueError where the reference raises inside the front smoother."""
+        from . import _capi
         sweeps, _ = self._vec.smooth_pave(iteration=iteration, interior=interior)
-        return int(sweeps.cpu()[0])
+        n = int(sweeps.cpu()[0])
+        if n == _capi.SMOOTH_RAISES:
+            raise ValueError("math domain error / division by zero inside smooth_current_boundary_3, as in the reference")
+        if n < 0:
+            raise RuntimeError(f"smooth_pave(): not applicable to this episode (code {n}: see _capi.SMOOTH_*)")
+        if not interior:
+            st = self._vec.get_state(0)
+            self.current_state = None if st["status"] & _capi.ST_NO_REFERENCE else self._vec.obs.cpu().numpy()[0].copy()
+        return n
 
     def smooth(self, vertices=None, lr_1=0.999, lr_2=0.999, iteration=400):
         """MeshGeneration.smooth, general/mesh.py:1290-1392, on a finished episode (general/EBRD.py:391); `vertices` is

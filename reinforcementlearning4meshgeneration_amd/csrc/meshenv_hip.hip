@@ -46,6 +46,7 @@ struct MeshEnv {
     long long launch_count = 0;
     std::vector<hipEvent_t> ev;  // 2 * MESHENV_TIMING_POOL events, created on first use
     int32_t *smooth_sweeps = nullptr;  // [E], allocated by the first meshenv_smooth: what the smoother did per env
+    int32_t *front_code = nullptr;     // [E] outcome of the front smoother (gates the interior pass of the same call)
     Reselect *pend = nullptr;          // [E] selection parked by the candidate rebuild (csrc/meshenv_smooth.h)
     float *pend_obs = nullptr;         // [E][18]
     bool reselect_pending = false;     // a rebuild ran since the last step kernel
@@ -541,39 +542,57 @@ int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, f
     return MESHENV_OK;
 }
 
-int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int interior, int32_t *sweeps_dev, double *diff_dev)
+int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int interior, int is_static, int32_t *sweeps_dev,
+                   double *diff_dev, float *obs_dev)
 {
     if (!h) return MESHENV_E_ARG;
-    if (!interior)
-        return fail_arg(h, "meshenv_smooth: interior = 0 (smooth_current_boundary_3 on the front, general/mesh.py:939-1028) is not built");
     if (iteration < 0) return fail_arg(h, "meshenv_smooth: iteration must be >= 0");
     const int log_cap = h->S.prm.log_cap;
     if (log_cap <= 0) {
         h->err = "meshenv_smooth: handle was created with log_capacity = 0 (the mesh graph is rebuilt from the element log)";
         return MESHENV_E_STATE;
     }
-    const size_t lds = smooth_lds_bytes(h->cap, log_cap);
-    if (lds > 160 * 1024 || h->cap + log_cap > 65535)
-        return fail_arg(h, "meshenv_smooth: ring stride + log_capacity too large for the smoother's LDS (16 B per ring slot + 60 B per logged vertex)");
+    const size_t lds = smooth_lds_bytes(h->cap, log_cap), lds_front = smooth_front_lds_bytes(h->cap, log_cap);
+    if (lds > 160 * 1024 || (!interior && lds_front > 160 * 1024) || h->cap + log_cap > 65535)
+        return fail_arg(h, "meshenv_smooth: ring stride + log_capacity too large for the smoother's LDS (16 B per ring slot + 60 B per logged vertex; front smoother 51 B per vertex)");
     MESHENV_ON_DEVICE(h);
     if (!h->smooth_sweeps) {
-        const int rc = dev_alloc(h, &h->smooth_sweeps, (size_t)h->n_envs);
+        int rc = dev_alloc(h, &h->smooth_sweeps, (size_t)h->n_envs);
+        if (rc != MESHENV_OK) return rc;
+        rc = dev_alloc(h, &h->front_code, (size_t)h->n_envs);
         if (rc != MESHENV_OK) return rc;
         HIP_TRY(h, hipFuncSetAttribute((const void *)k_smooth_interior, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        int rc2 = dev_alloc(h, &h->pend, (size_t)h->n_envs);
-        if (rc2 != MESHENV_OK) return rc2;
-        rc2 = dev_alloc(h, &h->pend_obs, (size_t)h->n_envs * kObsDim);
-        if (rc2 != MESHENV_OK) return rc2;
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_smooth_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        rc = dev_alloc(h, &h->pend, (size_t)h->n_envs);
+        if (rc != MESHENV_OK) return rc;
+        rc = dev_alloc(h, &h->pend_obs, (size_t)h->n_envs * kObsDim);
+        if (rc != MESHENV_OK) return rc;
         HIP_TRY(h, hipMemsetAsync(h->pend, 0xff, sizeof(Reselect) * (size_t)h->n_envs, h->stream));   // n_elem = -1: nothing parked
     }
     int32_t *sw = sweeps_dev ? sweeps_dev : h->smooth_sweeps;
-    hipLaunchKernelGGL(k_smooth_interior, dim3(h->n_envs), dim3(64), lds, h->stream, h->S, h->cap, mask_dev, iteration, sw, diff_dev);
+    const dim3 grid(h->n_envs), block(64);
+    if (!interior) {
+        hipLaunchKernelGGL(k_smooth_front, grid, block, lds_front, h->stream, h->S, h->cap, mask_dev, h->front_code);
+        HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_smooth_interior, grid, block, lds, h->stream, h->S, h->cap, mask_dev, interior ? nullptr : h->front_code,
+                       iteration, sw, diff_dev);
     HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL(k_rebuild_candidates, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend,
-                       h->pend_obs);
+    if (interior) {
+        hipLaunchKernelGGL(k_rebuild_candidates<0>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
+                           (float *)nullptr);
+        h->reselect_pending = true;
+    } else if (is_static) {
+        hipLaunchKernelGGL(k_rebuild_candidates<2>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
+                           obs_dev);
+    } else {
+        hipLaunchKernelGGL(k_rebuild_candidates<1>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
+                           obs_dev);
+    }
     HIP_TRY(h, hipGetLastError());
-    h->reselect_pending = true;
     return MESHENV_OK;
 }
 

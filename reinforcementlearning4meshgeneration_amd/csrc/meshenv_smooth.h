@@ -30,7 +30,7 @@ namespace meshenv {
 
 constexpr int kSmoothMaxDeg = 16;   // neighbours per generated vertex (a quad-mesh vertex has 3-6; more sets code -3)
 
-enum { kSmoothSkipped = -1, kSmoothLogOverflow = -2, kSmoothDegree = -3, kSmoothNotFinished = -4, kSmoothIndexError = -5 };
+enum { kSmoothSkipped = -1, kSmoothLogOverflow = -2, kSmoothDegree = -3, kSmoothNotFinished = -4, kSmoothIndexError = -5, kSmoothRaises = -6 };
 
 // LDS: coord[ring_cap + log_cap] double2 | xy_sum[log_cap] double | adj[log_cap][16] uint16 | lvl[log_cap] uint16 |
 //      deg[log_cap] uint8 | front[log_cap] uint8
@@ -101,13 +101,17 @@ __device__ __forceinline__ bool build_segment_lists(const int4 *__restrict__ qua
 // reference's loop), or kSmoothSkipped (masked out), kSmoothLogOverflow (graph incomplete: nothing changed),
 // kSmoothDegree.  diff_out[env]: the last |sum - previous sum| (the number the reference prints).
 __global__ void __launch_bounds__(64)
-k_smooth_interior(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int iteration, int32_t *__restrict__ sweeps_out,
-                  double *__restrict__ diff_out)
+k_smooth_interior(DevState S, int ring_cap, const uint8_t *__restrict__ mask, const int32_t *__restrict__ gate, int iteration,
+                  int32_t *__restrict__ sweeps_out, double *__restrict__ diff_out)
 {
     extern __shared__ double2 smem[];
     const int env = blockIdx.x, lane = lane_id();
     if (mask && mask[env] == 0) {
         if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothSkipped;
+        return;
+    }
+    if (gate && gate[env] < 0) {   // the front smoother (k_smooth_front) refused or raised: smooth_pave stops there
+        if (lane == 0 && sweeps_out) sweeps_out[env] = gate[env];
         return;
     }
     const int log_cap = S.prm.log_cap;
@@ -452,6 +456,355 @@ k_smooth_final(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int i
     }
 }
 
+// ------------------------------------------------------------------------------------------ the front smoother
+//
+// smooth_current_boundary_3, general/mesh.py:939-1028 (the interior=False half of smooth_pave, which move() enters when no
+// reference vertex is selectable, rl/boundary_env.py:405-412): every generated vertex ON the front, in ring order and in
+// place, by its interior angle -- <= 90: middle_vertex on the bisector for a target angle raised in steps of 5 until the
+// new position keeps every surrounding element on its side (is_inside_boundary over clockwise_vertices); (90, 180]:
+// side_vertex next to a sharp (< 45) neighbour corner, else find_indention_vertex; (180, 270]: find_indention_vertex;
+// beyond: inner_vertex, then find_indention_vertex.  A vertex sees its predecessors' new positions, so the front is
+// walked serially by the whole wavefront (wave-uniform control flow, LDS broadcast reads); the lanes carry the two
+// atan2-heavy inner loops -- one lane per entry of the surrounding polygon in is_inside_boundary, one lane per front
+// vertex / segment in find_indention_vertex's proximity tests.  Graph and coordinates as in k_smooth_final.
+
+struct FrontState {
+    double2 *coord;
+    const unsigned short *adj;
+    const unsigned char *deg;
+    const unsigned short *ringu;
+    int n;
+    bool raised;   // the reference raises here (math.sqrt of a negative number, division by zero)
+};
+
+__device__ __forceinline__ P2 ldc(const FrontState &f, int v)
+{
+    const double2 c = f.coord[v];
+    return mkp(c.x, c.y);
+}
+
+__device__ __forceinline__ double py_sqrt(FrontState &f, double v)
+{
+    if (v < 0) { f.raised = true; return 0.0; }
+    return sqrt(v);
+}
+
+__device__ __forceinline__ double py_div(FrontState &f, double a, double b)
+{
+    if (b == 0) { f.raised = true; return 0.0; }
+    return a / b;
+}
+
+__device__ __forceinline__ double deg2rad(double a) { return a * (kPi / 180.0); }   // math.radians
+__device__ __forceinline__ double rad2deg(double a) { return a * (180.0 / kPi); }   // math.degrees
+
+// the two intersections of the circle |p - (a, b)| = dist with the line A x + B y = W + A a + B b, M:841-858 / 889-904
+__device__ __forceinline__ void circle_line(FrontState &f, double a, double b, double A, double B, double W, double dist_,
+                                            P2 &v1, P2 &v2)
+{
+    if (B == 0) {
+        const double wa = py_div(f, W, A);
+        const double r = py_sqrt(f, dist_ * dist_ - wa * wa);
+        v1 = mkp(wa + a, b + r);
+        v2 = mkp(wa + a, b - r);
+    } else if (A == 0) {
+        const double wb = W / B;
+        const double r = py_sqrt(f, dist_ * dist_ - wb * wb);
+        v1 = mkp(a + r, wb + b);
+        v2 = mkp(a - r, wb + b);
+    } else {
+        const double M = -A / B;
+        const double N = (W + A * a + B * b) / B;
+        const double t = 2 * M * b - 2 * M * N + 2 * a;
+        const double disc = fabs(t * t - 4 * (M * M + 1) * ((N - b) * (N - b) + a * a - dist_ * dist_));
+        const double den = 2 * (M * M + 1);
+        const double sq = sqrt(disc);
+        v1.x = (t + sq) / den;
+        v2.x = (t - sq) / den;
+        v1.y = M * v1.x + N;
+        v2.y = M * v2.x + N;
+    }
+}
+
+// M:805-832
+__device__ __forceinline__ P2 middle_vertex(P2 vertex, P2 left, P2 right, double target_angle)
+{
+    const P2 m = mkp((left.x + right.x) / 2, (left.y + right.y) / 2);
+    const double A = right.x - left.x, B = right.y - left.y;
+    const double D = dist(left, m) / tan(deg2rad(target_angle / 2));
+    P2 v1, v2;
+    if (B == 0) {
+        v1 = mkp(m.x, m.y + D);
+        v2 = mkp(m.x, m.y - D);
+    } else if (A == 0) {
+        v1 = mkp(m.x + D, m.y);
+        v2 = mkp(m.x - D, m.y);
+    } else {
+        const double M = -A / B;
+        const double N = A * m.x / B + m.y;
+        const double t = -2 * M * N + 2 * m.x + 2 * M * m.y;
+        const double disc = fabs(t * t - 4 * (M * M + 1) * ((N - m.y) * (N - m.y) + m.x * m.x - D * D));
+        const double den = 2 * (M * M + 1);
+        const double sq = sqrt(disc);
+        v1.x = (t + sq) / den;
+        v2.x = (t - sq) / den;
+        v1.y = M * v1.x + N;
+        v2.y = M * v2.x + N;
+    }
+    return dist(v1, vertex) < dist(v2, vertex) ? v1 : v2;
+}
+
+// clockwise_vertices, M:1080-1101: the neighbours of `inner` sorted by clockwise angle (the selection sort as written),
+// each followed by the common neighbour it shares with its successor.  out (LDS, 2 x kSmoothMaxDeg): vertex indices.
+__device__ __forceinline__ int clockwise_vertices(const FrontState &f, int inner, unsigned short *out)
+{
+    int vs[kSmoothMaxDeg];
+    const int n = uniform_i32((int)f.deg[inner]);
+#pragma unroll
+    for (int j = 0; j < kSmoothMaxDeg; j++) vs[j] = j < n ? uniform_i32((int)f.adj[(size_t)inner * kSmoothMaxDeg + j]) : 0;
+    const P2 pin = ldc(f, inner);
+    const int lane = lane_id();
+    for (int i = 1; i < n; i++) {
+        // one lane per candidate j in [i, n): angle to the previous pick; the largest wins, the first among equals
+        int vj = 0, vp = 0;
+#pragma unroll
+        for (int j = 0; j < kSmoothMaxDeg; j++) {
+            vj = j == lane ? vs[j] : vj;
+            vp = j == i - 1 ? vs[j] : vp;
+        }
+        const bool act = lane >= i && lane < n;
+        const double a = act ? cw(pin, ldc(f, vj), ldc(f, vp)) : -2.0;
+        const double amax = -wave_min_f64(-a);
+        const unsigned long long hit = __ballot(act && a == amax);
+        const int flag = amax > -1 ? (int)__ffsll((long long)hit) - 1 : i;
+        if (flag != i) {
+            int t_i = 0, t_f = 0;
+#pragma unroll
+            for (int j = 0; j < kSmoothMaxDeg; j++) {
+                t_i = j == i ? vs[j] : t_i;
+                t_f = j == flag ? vs[j] : t_f;
+            }
+#pragma unroll
+            for (int j = 0; j < kSmoothMaxDeg; j++) vs[j] = j == i ? t_f : (j == flag ? t_i : vs[j]);
+        }
+    }
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        int cur = 0, prev = 0;
+        const int ip = i == 0 ? n - 1 : i - 1;
+#pragma unroll
+        for (int j = 0; j < kSmoothMaxDeg; j++) {
+            cur = j == i ? vs[j] : cur;
+            prev = j == ip ? vs[j] : prev;
+        }
+        int inter = -1;
+        const int dc = uniform_i32((int)f.deg[cur]), dp = uniform_i32((int)f.deg[prev]);
+        for (int j = 0; j < dc && inter < 0; j++) {
+            const int w = uniform_i32((int)f.adj[(size_t)cur * kSmoothMaxDeg + j]);
+            if (w == inner) continue;
+            bool have = false;
+            for (int q = 0; q < dp; q++) have = have || (int)f.adj[(size_t)prev * kSmoothMaxDeg + q] == w;
+            if (uniform_i32((int)have)) inter = w;
+        }
+        if (lane == 0) out[m] = (unsigned short)prev;
+        m += 1;
+        if (inter >= 0) {
+            if (lane == 0) out[m] = (unsigned short)inter;
+            m += 1;
+        }
+    }
+    wave_sync();
+    return m;
+}
+
+// is_inside_boundary, M:1069-1078: one lane per entry of the surrounding polygon
+__device__ __forceinline__ bool is_inside_boundary(const FrontState &f, P2 original, P2 moved, const unsigned short *b, int nb,
+                                                   int left, int right)
+{
+    const int lane = lane_id();
+    bool bad = false;
+    if (lane < nb) {
+        const int bi = b[lane], bp = b[lane == 0 ? nb - 1 : lane - 1];
+        const bool skip = (left == bi || left == bp) && (right == bi || right == bp);
+        if (!skip) bad = (cw(moved, ldc(f, bi), ldc(f, bp)) < kPi) != (cw(original, ldc(f, bi), ldc(f, bp)) < kPi);
+    }
+    return __ballot(bad) == 0ULL;
+}
+
+// M:911-937
+__device__ __forceinline__ P2 find_side_vertex(FrontState &f, int v, int _next, int next, int nn, double v_angle,
+                                               unsigned short *cb)
+{
+    const P2 pv = ldc(f, v), pn = ldc(f, next), pnn = ldc(f, nn);
+    const double d = (dist(pv, ldc(f, _next)) + dist(pv, pn) + dist(pn, pnn)) / 3;
+    double target = 45;
+    for (int guard = 0; guard < 16; guard++) {
+        const double W = d * dist(pn, pnn) * cos(deg2rad(target));
+        P2 v1, v2;
+        circle_line(f, pn.x, pn.y, pnn.x - pn.x, pnn.y - pn.y, W, d, v1, v2);
+        if (f.raised) return pv;
+        const P2 nv = dist(v1, pv) < dist(v2, pv) ? v1 : v2;
+        if (target <= v_angle) return pv;
+        const int nb = clockwise_vertices(f, v, cb);
+        if (is_inside_boundary(f, pv, nv, cb, nb, _next, next)) return nv;
+        target -= 5;
+    }
+    return pv;
+}
+
+// M:1030-1067 with indention_vertex M:882-909; index = ring slot of the vertex
+__device__ __forceinline__ P2 find_indention_vertex(FrontState &f, int index, double v_angle, unsigned short *cb)
+{
+    const int n = f.n, lane = lane_id();
+    const int v = f.ringu[index], left = f.ringu[wrapi(index + 1, n)], right = f.ringu[wrapi(index - 1, n)];
+    const int l2 = f.ringu[wrapi(index + 2, n)], r2 = f.ringu[wrapi(index - 2, n)];
+    const P2 pv = ldc(f, v), pl = ldc(f, left), pr = ldc(f, right);
+    const double d = (dist(pv, pl) + dist(pv, pr)) / 2;
+    bool near = false, zero_div = false;
+    for (int i = lane; i < n; i += 64) {
+        // Boundary2D.get_closet_points(front, vertex, [r2, right, left, l2], d): any other front vertex within d
+        const int w = f.ringu[i];
+        if (!(w == v || w == r2 || w == right || w == left || w == l2)) near = near || dist(pv, ldc(f, w)) <= d;
+        // find_closest_segments, M:1103-1112: a front segment not at the vertex whose foot point lies inside it, within d
+        const int p1 = f.ringu[i == 0 ? n - 1 : i - 1], p2 = w;
+        if (p1 != v && p2 != v) {
+            const P2 a = ldc(f, p1), b = ldc(f, p2);
+            const double A = b.x - a.x, B = b.y - a.y;
+            const double den = A * A + B * B;
+            if (den == 0) {
+                zero_div = true;
+            } else {
+                const double s = (A * pv.x + B * pv.y - B * a.y - A * a.x) / den;
+                near = near || (0 <= s && s <= 1 && dist(pv, mkp(a.x + s * A, a.y + s * B)) <= d);
+            }
+        }
+    }
+    // (the reference evaluates the vertex test first for all, then the segments in order: a zero-length segment raises
+    // only if it is reached, i.e. always -- both loops run to the end)
+    if (__ballot(zero_div) != 0ULL) { f.raised = true; return pv; }
+    if (__ballot(near) == 0ULL) return pv;
+    for (int times = 4; ; times++) {
+        const double dd = d / times;
+        const double W = dd * dist(pv, pl) * cos(deg2rad((360 - v_angle) / 2));
+        P2 v1, v2;
+        circle_line(f, pv.x, pv.y, pl.x - pv.x, pl.y - pv.y, W, dd, v1, v2);
+        if (f.raised) return pv;
+        const P2 nv = cw(v1, pl, pr) < cw(v2, pl, pr) ? v1 : v2;
+        if (times >= 10) return pv;
+        const int nb = clockwise_vertices(f, v, cb);
+        if (is_inside_boundary(f, pv, nv, cb, nb, left, right)) return nv;
+    }
+}
+
+// One wavefront per env: smooth_current_boundary_3 on the running episode's front.  code_out[env]: 0 done,
+// kSmoothSkipped / kSmoothLogOverflow / kSmoothDegree (untouched), kSmoothRaises (the reference raises: the vertices
+// moved before that point stay moved, as in the reference).
+__global__ void __launch_bounds__(64)
+k_smooth_front(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int32_t *__restrict__ code_out)
+{
+    extern __shared__ double2 smem[];
+    const int env = blockIdx.x, lane = lane_id();
+    if (mask && mask[env] == 0) {
+        if (lane == 0) code_out[env] = kSmoothSkipped;
+        return;
+    }
+    const int log_cap = S.prm.log_cap;
+    const EnvScalars sc = S.scal[env];
+    const DevCold cold = load_cold(S);
+    const int n = uniform_i32(sc.n), n_elem = uniform_i32(sc.n_elem), n_new = uniform_i32(sc.n_new);
+    const int status = uniform_i32(sc.status);
+    if ((status & kStLogOverflow) || n_elem > log_cap || n_new > log_cap) {
+        if (lane == 0) code_out[env] = kSmoothLogOverflow;
+        return;
+    }
+    const DomConst dc = S.dom[uniform_i32(sc.dom)];
+    const int doff = uniform_i32(dc.off), n0 = uniform_i32(dc.n0), nv = n0 + n_new;
+    const size_t lbase = ((size_t)env * 2 + ((status >> 4) & 1)) * log_cap;
+    const int4 *quads = reinterpret_cast<const int4 *>(cold.log_quads + lbase * 4);
+    double2 *vnew = cold.log_vxy + lbase;
+
+    const int V = ring_cap + log_cap;
+    double2 *coord = smem;
+    unsigned short *adj = (unsigned short *)(coord + V);
+    unsigned short *ringu = adj + (size_t)V * kSmoothMaxDeg;
+    unsigned short *cb = ringu + ring_cap;                          // clockwise_vertices output, 2 x kSmoothMaxDeg
+    unsigned char *deg = (unsigned char *)(cb + 2 * kSmoothMaxDeg);
+
+    for (int i = lane; i < n0; i += 64) coord[i] = cold.dom_xy[doff + i];
+    for (int k = lane; k < n_new; k += 64) coord[n0 + k] = vnew[k];
+    const int32_t *rid = S.ring_id + (size_t)env * S.cap;
+    for (int i = lane; i < n; i += 64) {
+        const int g = rid[i];
+        ringu[i] = (unsigned short)((g & kNewBit) ? n0 + (g & ~kNewBit) : g);
+    }
+    const bool too_many = build_segment_lists(quads, n_elem, n0, 0, nv, adj, deg, nullptr);
+    if (__ballot(too_many) != 0ULL) {
+        if (lane == 0) code_out[env] = kSmoothDegree;
+        return;
+    }
+    wave_sync();
+    FrontState f;
+    f.coord = coord; f.adj = adj; f.deg = deg; f.ringu = ringu; f.n = n; f.raised = false;
+    for (int i = 0; i < n && !f.raised; i++) {
+        const int v = uniform_i32((int)ringu[i]);
+        if (v < n0) continue;   // `in self.original_vertices`
+        const int nxt = uniform_i32((int)ringu[i + 1 == n ? 0 : i + 1]), prv = uniform_i32((int)ringu[i == 0 ? n - 1 : i - 1]);
+        const P2 pv = ldc(f, v), pn = ldc(f, nxt), pp = ldc(f, prv);
+        const double v_angle = rad2deg(cw(pv, pn, pp));
+        P2 nw = pv;
+        if (v_angle <= 90) {
+            double target = v_angle >= 45 ? v_angle : 45;
+            for (int guard = 0; guard < 24; guard++) {
+                const P2 cand = middle_vertex(pv, pn, pp, target);
+                if (target >= 135) break;
+                const int nb = clockwise_vertices(f, v, cb);
+                if (is_inside_boundary(f, pv, cand, cb, nb, nxt, prv)) { nw = cand; break; }
+                target += 5;
+            }
+        } else if (v_angle <= 180) {
+            const int nn_r = uniform_i32((int)ringu[wrapi(i - 2, n)]), nn_l = uniform_i32((int)ringu[wrapi(i + 2, n)]);
+            const double left_angle = rad2deg(cw(pn, ldc(f, nn_l), pv));    // compute_boundary_angle, C:467-473
+            const double right_angle = rad2deg(cw(pp, pv, ldc(f, nn_r)));
+            if (right_angle < 45) nw = find_side_vertex(f, v, nxt, prv, nn_r, right_angle, cb);
+            else if (left_angle < 45) nw = find_side_vertex(f, v, prv, nxt, nn_l, left_angle, cb);
+            else nw = find_indention_vertex(f, i, v_angle, cb);
+        } else if (v_angle <= 270) {
+            nw = find_indention_vertex(f, i, v_angle, cb);
+        } else {
+            // inner_vertex(vertex, 45), M:865-880
+            const P2 m = mkp((pn.x + pp.x) / 2, (pn.y + pp.y) / 2);
+            const double d = dist(m, pp) * tan(deg2rad(45.0));
+            const double A = pv.x - m.x, B = pv.y - m.y;
+            const double q = py_div(f, d * d, A * A + B * B);
+            if (f.raised) break;
+            const double s = sqrt(q);
+            if (lane == 0) coord[v] = make_double2(m.x + s * A, m.y + s * B);
+            wave_sync();
+            nw = find_indention_vertex(f, i, v_angle, cb);
+        }
+        if (f.raised) break;
+        if (lane == 0) coord[v] = make_double2(nw.x, nw.y);
+        wave_sync();
+    }
+    // the front's generated vertices moved: vertex log and ring copies
+    double2 *rxy = S.ring_xy + (size_t)env * S.cap;
+    for (int i = lane; i < n; i += 64) {
+        const int u = ringu[i];
+        if (u >= n0) {
+            const double2 c = coord[u];
+            vnew[u - n0] = c;
+            rxy[i] = c;
+        }
+    }
+    if (lane == 0) code_out[env] = f.raised ? kSmoothRaises : 0;
+}
+
+__host__ __device__ __forceinline__ size_t smooth_front_lds_bytes(int ring_cap, int log_cap)
+{
+    const size_t V = (size_t)ring_cap + log_cap;
+    return V * sizeof(double2) + V * kSmoothMaxDeg * 2 + (size_t)ring_cap * 2 + 2 * kSmoothMaxDeg * 2 + V + 64;
+}
+
 // What step()'s closing find_next_state (B:250) will select from the rebuilt list, computed at rebuild time.
 //
 // The reference re-selects the reference vertex from the candidate list at the end of EVERY step(), accepted or not; the
@@ -472,9 +825,13 @@ struct alignas(32) Reselect {
 // The point environment -- reference vertex, base length, observation -- is left alone, as in the reference, whose next
 // step() still acts on the reference vertex chosen before the call; the selection that step will end with is parked in
 // pend / pend_obs (above).
+// kMode 0: park the selection (above).  kMode 1 / 2: the front moved (smooth_pave(interior=False)), so the point
+// environment is recomputed at once -- the find_next_state() / find_next_state(static=True) that move() runs right after
+// smooth_pave (B:420) -- and committed: reference vertex, base length, action frame, observation (also to obs_out).
+template <int kMode>
 __global__ void __launch_bounds__(64)
 k_rebuild_candidates(DevState S, int cap, const uint8_t *__restrict__ mask, const int32_t *__restrict__ sweeps,
-                     Reselect *__restrict__ pend, float *__restrict__ pend_obs)
+                     Reselect *__restrict__ pend, float *__restrict__ pend_obs, float *__restrict__ obs_out)
 {
     extern __shared__ double2 smem[];
     const int env = blockIdx.x;
@@ -501,14 +858,20 @@ k_rebuild_candidates(DevState S, int cap, const uint8_t *__restrict__ mask, cons
     BqArgs bq;
     bq.skip = false;
     bq.mode = 0; bq.a = 0; bq.b = 0; bq.ang0 = 0; bq.ang1 = 0; bq.q_ang0 = 0; bq.q_ang2 = 0; bq.half01 = 0; bq.half23 = 0;
-    find_next_state(c, S, bq);
-    if (c.lane < kObsDim) pend_obs[(size_t)env * kObsDim + c.lane] = c.obs;
-    if (c.lane == 0) {
-        Reselect r;
-        r.n_elem = c.n_elem; r.ref = c.ref; r.bl = c.bl; r.ct = c.ct; r.st = c.st;
-        pend[env] = r;
+    find_next_state(c, S, bq, kMode == 2);
+    if (kMode == 0) {
+        if (c.lane < kObsDim) pend_obs[(size_t)env * kObsDim + c.lane] = c.obs;
+        if (c.lane == 0) {
+            Reselect r;
+            r.n_elem = c.n_elem; r.ref = c.ref; r.bl = c.bl; r.ct = c.ct; r.st = c.st;
+            pend[env] = r;
+        }
+        c.ref = ref0; c.status = status0; c.bl = bl0; c.ct = ct0; c.st = st0; c.obs = obs0;
+    } else {
+        c.status &= ~(kStRm1Bad | kStRp1Bad);   // the memo of rejected quads is tied to the reference vertex and the ring
+        if (c.lane == 0) pend[env].n_elem = -1;
+        if (obs_out && c.lane < kObsDim) obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
     }
-    c.ref = ref0; c.status = status0; c.bl = bl0; c.ct = ct0; c.st = st0; c.obs = obs0;
     c.ring_dirty = true;
     store_env(c, S);
 }

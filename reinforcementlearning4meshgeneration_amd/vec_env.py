@@ -271,15 +271,19 @@ class MeshVecEnv:
         self._check(rc, "meshenv_move")
         return self.obs, self.done, self.complete, self.move_code
 
-    def smooth_pave(self, mask=None, iteration: int = 400, interior: bool = True):
-        """MeshGeneration.smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=iteration, interior=True)
-        (general/mesh.py:790-795) on the running episode of every env (mask: uint8/bool CUDA [n], None = all): the
-        generated vertices off the front are relaxed (smooth_fixed_vertices) and the candidate list is rebuilt; the vertex
-        log (`generated_meshes`, the quality report) then holds the moved coordinates.  Needs log_capacity > 0.
-        Returns (sweeps int32 [n], diff float64 [n]); sweeps < 0: _capi.SMOOTH_* (env untouched).  interior=False (the
-        front smoother smooth_current_boundary_3) is not built and raises NotImplementedError."""
-        if not interior:
-            raise NotImplementedError("smooth_pave(interior=False): smooth_current_boundary_3 (general/mesh.py:939-1028) is not built")
+    def smooth_pave(self, mask=None, iteration: int = 400, interior: bool = True, static: bool = False):
+        """MeshGeneration.smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=iteration, interior=interior)
+        (general/mesh.py:790-795) on the running episode of every env (mask: uint8/bool CUDA [n], None = all).  Needs
+        log_capacity > 0; the vertex log (`generated_meshes`, the quality report) holds the moved coordinates afterwards.
+
+        interior=True (general/EBRD.py:393): the generated vertices off the front are relaxed (smooth_fixed_vertices) and
+        the candidate list is rebuilt; reference vertex and observation stay as they are, like in the reference.
+        interior=False (what move() runs, rl/boundary_env.py:405-420): smooth_current_boundary_3 moves the front's
+        generated vertices first; then, the front having moved, the point environment is recomputed at once
+        (find_next_state(static=static)) and `self.obs` holds its observation.
+
+        Returns (sweeps int32 [n], diff float64 [n]); sweeps < 0: _capi.SMOOTH_* (SMOOTH_RAISES: the reference raises
+        inside the front smoother; the env keeps what had moved until then)."""
         t = self._torch
         if not hasattr(self, "smooth_sweeps"):
             self.smooth_sweeps = t.zeros(self.num_envs, dtype=t.int32, device=self.device)
@@ -291,8 +295,9 @@ class MeshVecEnv:
                 raise ValueError(f"mask must have shape ({self.num_envs},)")
             mptr = mask.data_ptr()
         self._bind_stream()
-        rc = self._L.meshenv_smooth(self._handle, mptr, int(iteration), 1, self.smooth_sweeps.data_ptr(),
-                                    self.smooth_diff.data_ptr())
+        rc = self._L.meshenv_smooth(self._handle, mptr, int(iteration), 1 if interior else 0, 1 if static else 0,
+                                    self.smooth_sweeps.data_ptr(), self.smooth_diff.data_ptr(),
+                                    None if interior else self.obs.data_ptr())
         self._check(rc, "meshenv_smooth")
         return self.smooth_sweeps, self.smooth_diff
 
