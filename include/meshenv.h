@@ -199,10 +199,18 @@ enum {
     MESHENV_MOVE_RAISES = 2,          /* ring <= 5 (or no reference vertex) on entry: the reference raises
                                          UnboundLocalError (`is_complete` unbound, rl/boundary_env.py:283-285, 432);
                                          nothing is changed, the cached observation is returned */
-    MESHENV_MOVE_NEEDS_SMOOTHING = 3  /* no selectable reference vertex on a ring of more than 4: the reference runs
-                                         smooth_pave (general/mesh.py:1100-1392, not built here) and retries; this
-                                         library ends the episode instead: done = 1, complete = 0 */
+    MESHENV_MOVE_NEEDS_SMOOTHING = 3, /* only on handles without a usable element log (log_capacity = 0, overflow, or
+                                         too large for the smoother's LDS): the smooth_pave below cannot be run and the
+                                         episode ends instead, done = 1, complete = 0 */
+    MESHENV_MOVE_SMOOTH_RAISES = 4    /* the reference raises inside that smooth_pave (math domain error / division by
+                                         zero in a vertex construction): done = 1, the caller resets */
 };
+/* No selectable reference vertex on a front of more than 4 vertices (every candidate is listed in not_valid_points):
+ * the reference runs smooth_pave (front + interior smoothing, candidate rebuild; rl/boundary_env.py:405-412), ends the
+ * episode if not_valid_points repeats the list of the previous such smoothing (first entry, last entry and length;
+ * last_not_valid_points survives reset(), :416-420), empties the list and selects again (:422-426).  meshenv_move does
+ * the same in the same call (the kernels of meshenv_smooth under a mask of those envs); such a move returns
+ * MESHENV_MOVE_OK / MESHENV_MOVE_NONE like any other. */
 int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, float *obs_dev, uint8_t *done_dev,
                  uint8_t *complete_dev, uint8_t *code_dev);
 

@@ -69,7 +69,11 @@ struct RefEnv {
     double orig_area, min_l, crit_l;
     /* move() API: not_valid_points (B:47, reference points of rejected moves; matched by distance < 0.001, M:428-433) */
     P2 *nv;
+    int32_t *nv_id;    /* global vertex id of each listed vertex (the list holds Vertex objects: identity) */
     int n_nv;
+    /* last_not_valid_points (B:48, 416-422): set only where move() smooths, NOT cleared by reset() -- first / last entry
+     * and length are all the reference compares; a generated vertex is the same object only within one episode */
+    int32_t last_first, last_last, last_count, last_epoch, epoch;
     /* logs */
     int cap_v, cap_e;
     P2 *vtab;
@@ -642,7 +646,10 @@ RefEnv *meshenv_ref_create(int n0, const double *xy, double original_area, doubl
     e->key = (double *)malloc(sizeof(double) * n0);
     e->stamp = (int64_t *)malloc(sizeof(int64_t) * n0);
     e->nv = (P2 *)malloc(sizeof(P2) * (size_t)(n0 + 8));
+    e->nv_id = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n0 + 8));
     e->n_nv = 0;
+    e->last_count = 0;
+    e->epoch = 0;
     for (int i = 0; i < n0; i++) {
         e->ring0[i].x = xy[2 * i];
         e->ring0[i].y = xy[2 * i + 1];
@@ -663,7 +670,7 @@ void meshenv_ref_destroy(RefEnv *e)
 {
     if (!e) return;
     free(e->ring); free(e->ring0); free(e->rid); free(e->cand); free(e->key); free(e->stamp);
-    free(e->vtab); free(e->quads); free(e->nv); free(e);
+    free(e->vtab); free(e->quads); free(e->nv); free(e->nv_id); free(e);
 }
 
 /* B:84-101 */
@@ -682,6 +689,7 @@ int meshenv_ref_reset_static(RefEnv *e, float *obs, int is_static)
     e->failed = 0;
     e->cur_area = e->orig_area;
     e->n_nv = 0; /* self.not_valid_points = [], B:90 */
+    e->epoch += 1;
     find_reference_candidates(e);
     return find_next_state_opt(e, obs, is_static, 0);
 }
@@ -821,9 +829,11 @@ static double round6_py(double x)
  * bookkeeping; rejected reference vertices accumulate in not_valid_points and are skipped by the next selection; the
  * observation is the static one.
  * Returns MESHENV_REF_MOVE_*: OK, NONE (obs is None; only possible with ring <= 4 here), RAISES (ring <= 5 on entry:
- * the reference leaves `is_complete` unbound and raises UnboundLocalError; nothing is changed), NEEDS_SMOOTHING (no
- * reference vertex is left while the ring has more than 4 vertices: the reference runs smooth_pave (M:1100-1392, not
- * built) and retries; here the move ends the episode as not complete). */
+ * the reference leaves `is_complete` unbound and raises UnboundLocalError; nothing is changed).  When no reference vertex is
+ * left while the ring has more than 4 vertices the reference runs smooth_pave (front + interior smoothing, candidate
+ * rebuild; B:405-412), ends the episode if not_valid_points repeats the list of the previous smoothing (B:416-420;
+ * last_not_valid_points survives reset()), empties the list and selects again (B:422-426): done here as well;
+ * SMOOTH_RAISES where the reference raises inside smooth_pave, NEEDS_SMOOTHING only if the element log overflowed. */
 int meshenv_ref_move(RefEnv *e, const double *point, double type, float *obs, uint8_t *done_out, uint8_t *complete_out)
 {
     if (e->n <= 5 || e->ref < 0) return MESHENV_REF_MOVE_RAISES;
@@ -873,7 +883,10 @@ int meshenv_ref_move(RefEnv *e, const double *point, double type, float *obs, ui
         int listed = 0;
         for (int k = 0; k < e->n_nv; k++)
             if (e->nv[k].x == reference_point.x && e->nv[k].y == reference_point.y) listed = 1;
-        if (!listed) e->nv[e->n_nv++] = reference_point;
+        if (!listed) {
+            e->nv[e->n_nv] = reference_point;
+            e->nv_id[e->n_nv++] = e->rid[index];
+        }
         none = find_next_state_opt(e, obs, 1, 1);
     } else {
         e->n_nv = 0; /* B:382 */
@@ -881,9 +894,28 @@ int meshenv_ref_move(RefEnv *e, const double *point, double type, float *obs, ui
     int is_complete, rc = none ? MESHENV_REF_MOVE_NONE : MESHENV_REF_MOVE_OK;
     if (e->n > 4) {
         is_complete = 0;
-        if (none) { /* B:421-443: smooth_pave + retry in the reference */
-            done = 1;
-            rc = MESHENV_REF_MOVE_NEEDS_SMOOTHING;
+        if (none) { /* B:405-426: smooth_pave, then a fresh selection with an empty not_valid_points */
+            int32_t sweeps = 0;
+            int src = meshenv_ref_smooth_front(e);
+            if (src == -3) { *done_out = (uint8_t)done; *complete_out = 0; return MESHENV_REF_MOVE_SMOOTH_RAISES; }
+            if (src == 0) src = meshenv_ref_smooth_interior(e, 400, &sweeps, NULL);
+            if (src != 0) { /* log overflow: the graph cannot be rebuilt -- the episode ends here (not a reference path) */
+                *done_out = 1; *complete_out = 0;
+                return MESHENV_REF_MOVE_NEEDS_SMOOTHING;
+            }
+            if (e->last_count > 0 && e->n_nv > 0) {
+                const int32_t f = e->nv_id[0], l = e->nv_id[e->n_nv - 1];
+                const int same_f = f == e->last_first && (f < e->n0 || e->last_epoch == e->epoch);
+                const int same_l = l == e->last_last && (l < e->n0 || e->last_epoch == e->epoch);
+                if (same_f && same_l && e->n_nv == e->last_count) done = 1;
+            }
+            e->last_count = e->n_nv;
+            if (e->n_nv > 0) { e->last_first = e->nv_id[0]; e->last_last = e->nv_id[e->n_nv - 1]; }
+            e->last_epoch = e->epoch;
+            e->n_nv = 0;
+            none = find_next_state_opt(e, obs, 1, 1);
+            if (none) done = 1;
+            rc = none ? MESHENV_REF_MOVE_NONE : MESHENV_REF_MOVE_OK;
         }
     } else {
         is_complete = 1;

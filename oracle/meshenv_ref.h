@@ -50,7 +50,11 @@ int meshenv_ref_reset_static(RefEnv *e, float *obs, int is_static);
 
 /* move(new_point, type), rl/boundary_env.py:265-432 (the deterministic API the ANN / testbed scripts drive), for
  * Python-float arguments.  point[2] = (radius fraction, angle); see meshenv_ref.c for the return codes. */
-enum { MESHENV_REF_MOVE_OK = 0, MESHENV_REF_MOVE_NONE = 1, MESHENV_REF_MOVE_RAISES = 2, MESHENV_REF_MOVE_NEEDS_SMOOTHING = 3 };
+enum {
+    MESHENV_REF_MOVE_OK = 0, MESHENV_REF_MOVE_NONE = 1, MESHENV_REF_MOVE_RAISES = 2,
+    MESHENV_REF_MOVE_NEEDS_SMOOTHING = 3, /* only when the element log overflowed: smooth_pave cannot be run (episode ends) */
+    MESHENV_REF_MOVE_SMOOTH_RAISES = 4    /* the reference raises inside smooth_pave (math domain error / division by zero) */
+};
 int meshenv_ref_move(RefEnv *e, const double *point, double type, float *obs, uint8_t *done, uint8_t *is_complete);
 int meshenv_ref_not_valid_count(const RefEnv *e);
 

@@ -224,14 +224,21 @@ def move_inputs(seed: int, T: int):
 def record_move_trace(points, pts: np.ndarray, types: np.ndarray, static_reset: bool = True,
                       reset_on_done: bool = True) -> dict:
     """Drive the reference's move() with Python floats and record what parity needs.  A call the reference cannot answer
-    is recorded by its code: 2 = it raises UnboundLocalError (ring <= 5 on entry), 3 = it enters smooth_pave."""
+    is recorded by its code: 2 = it raises UnboundLocalError (ring <= 5 on entry), 4 = it raises inside smooth_pave
+    (math domain error / division by zero); `smoothed` marks the calls that went through smooth_pave (B:405-426)."""
+    import contextlib
+    import io
     env = make_env(points)
     n0 = len(points)
     T = len(pts)
+    smoothed_flag = [0]
+    orig_smooth = env.smooth_pave
 
-    def _patched(*a, **k):
-        raise _NeedsSmoothing()
-    env.smooth_pave = _patched
+    def _counting(*a, **k):
+        smoothed_flag[0] = 1
+        with contextlib.redirect_stdout(io.StringIO()):
+            return orig_smooth(*a, **k)
+    env.smooth_pave = _counting
 
     def ids_of(vlist):
         table = {id(v): k for k, v in enumerate(env.boundary.vertices)}
@@ -243,10 +250,12 @@ def record_move_trace(points, pts: np.ndarray, types: np.ndarray, static_reset: 
         complete=np.zeros(T, np.uint8), ring_len=np.zeros(T, np.int32), ring_ids=np.full((T, n0), -1, np.int32),
         ref_id=np.full(T, -1, np.int32), n_elem=np.zeros(T, np.int32), n_not_valid=np.zeros(T, np.int32),
         new_xy=np.full((T, 2), np.nan, np.float64), valid=np.zeros(T, np.uint8), was_reset=np.zeros(T, np.uint8),
+        smoothed=np.zeros(T, np.uint8),
     )
     for t in range(T):
         nverts_before = len(env.boundary.vertices)
         nelem_before = len(env.generated_meshes)
+        smoothed_flag[0] = 0
         try:
             obs, rew, done, info = env.move([float(pts[t, 0]), float(pts[t, 1])], float(types[t]))
             assert rew == 0
@@ -254,9 +263,11 @@ def record_move_trace(points, pts: np.ndarray, types: np.ndarray, static_reset: 
             comp = info["is_complete"]
         except UnboundLocalError:
             obs, done, comp, code = None, False, False, 2
-        except _NeedsSmoothing:
-            obs, done, comp, code = None, True, False, 3
+        except (ValueError, ZeroDivisionError):
+            assert smoothed_flag[0]
+            obs, done, comp, code = None, True, False, 4
         out["code"][t] = code
+        out["smoothed"][t] = smoothed_flag[0]
         if obs is not None:
             out["obs"][t] = obs
         out["done"][t] = done

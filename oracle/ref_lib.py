@@ -141,7 +141,7 @@ class RefEnv:
         none = self.L.meshenv_ref_reset_static(self.h, self._obs, int(bool(static)))
         return self._obs.copy(), bool(none)
 
-    MOVE_OK, MOVE_NONE, MOVE_RAISES, MOVE_NEEDS_SMOOTHING = 0, 1, 2, 3
+    MOVE_OK, MOVE_NONE, MOVE_RAISES, MOVE_NEEDS_SMOOTHING, MOVE_SMOOTH_RAISES = 0, 1, 2, 3, 4
 
     def move(self, point, type_):
         """move((radius fraction, angle), type) -> (obs, done, is_complete, code); code as MESHENV_REF_MOVE_*."""

@@ -24,11 +24,13 @@ from .vec_env import MeshVecEnv, make_spaces
 
 
 class BoudaryEnv:  # the reference's spelling
+    # log_capacity: elements / generated vertices kept per episode (`generated_meshes`); 1024 keeps the smoothers'
+    # per-env graph (csrc/meshenv_smooth.h: ~60 B per logged vertex) inside one CU's 160 KB of LDS for rings up to ~1500
     metadata = {"render.modes": ["human"]}
     TYPE_THRESHOLD = 0.3
 
     def __init__(self, boundary: Sequence[Point], experiment_version=None, env_name=None, *, device: int = 0,
-                 api: str = "legacy", log_capacity: int = 4096):
+                 api: str = "legacy", log_capacity: int = 1024):
         if hasattr(boundary, "vertices"):  # a reference-style Boundary2D
             boundary = [(v.x, v.y) for v in boundary.vertices]
         if api not in ("legacy", "gymnasium"):
@@ -75,10 +77,11 @@ class BoudaryEnv:  # the reference's spelling
 
     def move(self, new_point, type, lr_1=None, lr_2=None):
         """rl/boundary_env.py:265-432: deterministic extraction driven by (radius fraction, angle) and a rule selector;
-        returns (obs | None, 0, done, {'is_complete': bool}) like the reference.  Two of its paths differ by necessity:
-        on a finished ring (<= 5 vertices) the reference leaves `is_complete` unbound and raises UnboundLocalError --
-        so does this; where the reference would run smooth_pave (no selectable reference vertex on a ring of more than
-        4; the smoothing is not built) the episode ends here with done = True, is_complete = False."""
+        returns (obs | None, 0, done, {'is_complete': bool}) like the reference, including its two exceptions: on a
+        finished ring (<= 5 vertices) it leaves `is_complete` unbound and raises UnboundLocalError -- so does this; and
+        where it raises inside the smooth_pave it runs when no reference vertex is selectable (math domain error /
+        division by zero in a vertex construction) this raises ValueError.  That smooth_pave itself (front + interior
+        smoothing, candidate rebuild, the last_not_valid_points check) runs on the device inside the same call."""
         import torch
 
         from . import _capi
@@ -89,6 +92,8 @@ class BoudaryEnv:  # the reference's spelling
         if code == _capi.MOVE_RAISES:
             raise UnboundLocalError("local variable 'is_complete' referenced before assignment "
                                     "(move() on a ring of <= 5 vertices, as in the reference)")
+        if code == _capi.MOVE_SMOOTH_RAISES:
+            raise ValueError("math domain error / division by zero inside smooth_pave, as in the reference")
         obs_np = obs.cpu().numpy()[0].copy() if code == _capi.MOVE_OK else None
         self.current_state = obs_np
         return obs_np, 0, bool(done.cpu()[0]), {"is_complete": bool(comp.cpu()[0])}

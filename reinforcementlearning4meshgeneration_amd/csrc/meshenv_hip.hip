@@ -54,6 +54,9 @@ struct MeshEnv {
     // move() API state, allocated by the first meshenv_move: not_valid_points per env
     double2 *nv_xy = nullptr;    // [E][cap]
     int32_t *nv_count = nullptr; // [E]
+    int32_t *nv_gid = nullptr;   // [E][cap] ring id of each listed vertex (identity, for last_not_valid_points)
+    int32_t *nv_meta = nullptr;  // [E][kNvMeta] episode counter + last_not_valid_points summary
+    uint8_t *move_mask = nullptr;  // [E] envs of the last meshenv_move that went through smooth_pave
     long long ev_count = 0;      // launches recorded since timing was armed
 };
 
@@ -385,7 +388,7 @@ static int create_impl(int device, int n_domains, const int32_t *dom_offsets_hos
     hipLaunchKernelGGL(k_init_domains, dim3(n_domains), dim3(64), lds, h->stream, S, cap);
     CREATE_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_reset, dim3(n_envs), dim3(64), lds, h->stream, S, cap, (const uint8_t *)nullptr, (float *)nullptr, 1, 0ULL,
-                       0, (int32_t *)nullptr);
+                       0, (int32_t *)nullptr, (int32_t *)nullptr);
     CREATE_HIP(hipGetLastError());
     CREATE_HIP(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
@@ -502,12 +505,64 @@ int meshenv_reset_static(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev, in
     if (!h) return MESHENV_E_ARG;
     MESHENV_ON_DEVICE(h);
     hipLaunchKernelGGL(k_reset, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, mask_dev, obs_dev, 0,
-                       (unsigned long long)h->steps_done, is_static ? 1 : 0, h->nv_count);
+                       (unsigned long long)h->steps_done, is_static ? 1 : 0, h->nv_count, h->nv_meta);
     HIP_TRY(h, hipGetLastError());
     return MESHENV_OK;
 }
 
 int meshenv_reset(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev) { return meshenv_reset_static(h, mask_dev, obs_dev, 0); }
+
+// buffers and kernel attributes of the smoothing entry points, on first use
+static int ensure_smooth_state(MeshEnv *h)
+{
+    if (h->smooth_sweeps) return MESHENV_OK;
+    int rc = dev_alloc(h, &h->smooth_sweeps, (size_t)h->n_envs);
+    if (rc != MESHENV_OK) return rc;
+    rc = dev_alloc(h, &h->front_code, (size_t)h->n_envs);
+    if (rc != MESHENV_OK) return rc;
+    HIP_TRY(h, hipFuncSetAttribute((const void *)k_smooth_interior, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute((const void *)k_smooth_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    rc = dev_alloc(h, &h->pend, (size_t)h->n_envs);
+    if (rc != MESHENV_OK) return rc;
+    rc = dev_alloc(h, &h->pend_obs, (size_t)h->n_envs * kObsDim);
+    if (rc != MESHENV_OK) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->pend, 0xff, sizeof(Reselect) * (size_t)h->n_envs, h->stream));   // n_elem = -1: nothing parked
+    return MESHENV_OK;
+}
+
+// smooth_pave(interior=False) + find_next_state(static = is_static) for the envs of `mask_dev`; sw: [E] outcome
+static int launch_full_smoothing(MeshEnv *h, const uint8_t *mask_dev, int iteration, int is_static, int32_t *sw, double *diff_dev,
+                                 float *obs_dev)
+{
+    MESHENV_ON_DEVICE(h);
+    const int log_cap = h->S.prm.log_cap;
+    const dim3 grid(h->n_envs), block(64);
+    hipLaunchKernelGGL(k_smooth_front, grid, block, smooth_front_lds_bytes(h->cap, log_cap), h->stream, h->S, h->cap, mask_dev,
+                       h->front_code);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(k_smooth_interior, grid, block, smooth_lds_bytes(h->cap, log_cap), h->stream, h->S, h->cap, mask_dev,
+                       h->front_code, iteration, sw, diff_dev);
+    HIP_TRY(h, hipGetLastError());
+    if (is_static)
+        hipLaunchKernelGGL(k_rebuild_candidates<2>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
+                           obs_dev);
+    else
+        hipLaunchKernelGGL(k_rebuild_candidates<1>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
+                           obs_dev);
+    HIP_TRY(h, hipGetLastError());
+    return MESHENV_OK;
+}
+
+static bool smoothing_fits(const MeshEnv *h, bool with_front)
+{
+    const int log_cap = h->S.prm.log_cap;
+    if (log_cap <= 0 || h->cap + log_cap > 65535) return false;
+    if (smooth_lds_bytes(h->cap, log_cap) > 160 * 1024) return false;
+    return !with_front || smooth_front_lds_bytes(h->cap, log_cap) <= 160 * 1024;
+}
 
 static int ensure_move_state(MeshEnv *h)
 {
@@ -518,6 +573,13 @@ static int ensure_move_state(MeshEnv *h)
     rc = dev_alloc(h, &h->nv_count, (size_t)h->n_envs);
     if (rc != MESHENV_OK) return rc;
     HIP_TRY(h, hipMemsetAsync(h->nv_count, 0, sizeof(int32_t) * (size_t)h->n_envs, h->stream));
+    rc = dev_alloc(h, &h->nv_gid, total);
+    if (rc != MESHENV_OK) return rc;
+    rc = dev_alloc(h, &h->nv_meta, (size_t)h->n_envs * kNvMeta);
+    if (rc != MESHENV_OK) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->nv_meta, 0, sizeof(int32_t) * (size_t)h->n_envs * kNvMeta, h->stream));
+    rc = dev_alloc(h, &h->move_mask, (size_t)h->n_envs);
+    if (rc != MESHENV_OK) return rc;
     if (move_lds_bytes(h->cap) > 64 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)k_move, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return MESHENV_OK;
@@ -533,8 +595,21 @@ int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, f
     const int rc = ensure_move_state(h);
     if (rc != MESHENV_OK) return rc;
     hipLaunchKernelGGL(k_move, dim3(h->n_envs), dim3(64), move_lds_bytes(h->cap), h->stream, h->S, h->cap, points_dev, type_dev,
-                       obs_dev, done_dev, complete_dev, code_dev, h->nv_xy, h->nv_count);
+                       obs_dev, done_dev, complete_dev, code_dev, h->nv_xy, h->nv_count, h->nv_gid);
     HIP_TRY(h, hipGetLastError());
+    if (smoothing_fits(h, true)) {
+        // B:405-426: the envs k_move left at "no selectable reference vertex" go through smooth_pave and select again
+        const int rcs = ensure_smooth_state(h);
+        if (rcs != MESHENV_OK) return rcs;
+        const int nb = (h->n_envs + 255) / 256;
+        hipLaunchKernelGGL(k_move_mask, dim3(nb), dim3(256), 0, h->stream, code_dev, h->move_mask, h->n_envs);
+        HIP_TRY(h, hipGetLastError());
+        const int rcf = launch_full_smoothing(h, h->move_mask, 400, 1, h->smooth_sweeps, nullptr, obs_dev);
+        if (rcf != MESHENV_OK) return rcf;
+        hipLaunchKernelGGL(k_move_finish, dim3(nb), dim3(256), 0, h->stream, h->S, h->cap, h->move_mask, h->smooth_sweeps, h->nv_count,
+                           h->nv_gid, h->nv_meta, done_dev, complete_dev, code_dev);
+        HIP_TRY(h, hipGetLastError());
+    }
     if (h->reselect_pending) {  // move() ends with its own selection from the list, accepted or not: nothing stays parked
         HIP_TRY(h, hipMemsetAsync(h->pend, 0xff, sizeof(Reselect) * (size_t)h->n_envs, h->stream));
         h->reselect_pending = false;
@@ -556,43 +631,20 @@ int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int inter
     if (lds > 160 * 1024 || (!interior && lds_front > 160 * 1024) || h->cap + log_cap > 65535)
         return fail_arg(h, "meshenv_smooth: ring stride + log_capacity too large for the smoother's LDS (16 B per ring slot + 60 B per logged vertex; front smoother 51 B per vertex)");
     MESHENV_ON_DEVICE(h);
-    if (!h->smooth_sweeps) {
-        int rc = dev_alloc(h, &h->smooth_sweeps, (size_t)h->n_envs);
+    {
+        const int rc = ensure_smooth_state(h);
         if (rc != MESHENV_OK) return rc;
-        rc = dev_alloc(h, &h->front_code, (size_t)h->n_envs);
-        if (rc != MESHENV_OK) return rc;
-        HIP_TRY(h, hipFuncSetAttribute((const void *)k_smooth_interior, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(h, hipFuncSetAttribute((const void *)k_smooth_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        rc = dev_alloc(h, &h->pend, (size_t)h->n_envs);
-        if (rc != MESHENV_OK) return rc;
-        rc = dev_alloc(h, &h->pend_obs, (size_t)h->n_envs * kObsDim);
-        if (rc != MESHENV_OK) return rc;
-        HIP_TRY(h, hipMemsetAsync(h->pend, 0xff, sizeof(Reselect) * (size_t)h->n_envs, h->stream));   // n_elem = -1: nothing parked
     }
     int32_t *sw = sweeps_dev ? sweeps_dev : h->smooth_sweeps;
+    if (!interior) return launch_full_smoothing(h, mask_dev, iteration, is_static, sw, diff_dev, obs_dev);
     const dim3 grid(h->n_envs), block(64);
-    if (!interior) {
-        hipLaunchKernelGGL(k_smooth_front, grid, block, lds_front, h->stream, h->S, h->cap, mask_dev, h->front_code);
-        HIP_TRY(h, hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_smooth_interior, grid, block, lds, h->stream, h->S, h->cap, mask_dev, interior ? nullptr : h->front_code,
-                       iteration, sw, diff_dev);
+    hipLaunchKernelGGL(k_smooth_interior, grid, block, lds, h->stream, h->S, h->cap, mask_dev, (const int32_t *)nullptr, iteration, sw,
+                       diff_dev);
     HIP_TRY(h, hipGetLastError());
-    if (interior) {
-        hipLaunchKernelGGL(k_rebuild_candidates<0>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
-                           (float *)nullptr);
-        h->reselect_pending = true;
-    } else if (is_static) {
-        hipLaunchKernelGGL(k_rebuild_candidates<2>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
-                           obs_dev);
-    } else {
-        hipLaunchKernelGGL(k_rebuild_candidates<1>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
-                           obs_dev);
-    }
+    hipLaunchKernelGGL(k_rebuild_candidates<0>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
+                       (float *)nullptr);
     HIP_TRY(h, hipGetLastError());
+    h->reselect_pending = true;
     return MESHENV_OK;
 }
 

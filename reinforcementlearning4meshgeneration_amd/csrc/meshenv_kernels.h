@@ -27,6 +27,7 @@ constexpr int kStLogOverflow = 2;
 // boundary intersection test are pure functions of the state, so a repeated attempt needs no geometry at all);
 // cleared whenever the state changes (extraction, reset)
 constexpr int kStRm1Bad = 4, kStRp1Bad = 8;
+constexpr int kNvMeta = 8;   // int32 words of move() bookkeeping per env: episode counter | last_not_valid_points: first id, last id, length, its episode
 constexpr int kStLogHalf = 16;  // which half of the element / vertex log the running episode writes
 
 // scratch area appended to the LDS ring arrays
@@ -1543,7 +1544,8 @@ __global__ void __launch_bounds__(64) k_init_domains(DevState S, int cap)
 }
 
 __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t *mask, float *obs_out, int first,
-                                               unsigned long long step_now, int is_static, int32_t *nv_count)
+                                               unsigned long long step_now, int is_static, int32_t *nv_count,
+                                               int32_t *nv_meta)
 {
     extern __shared__ double2 smem[];
     Ctx c;
@@ -1569,7 +1571,10 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
     const int n_old = c.n;
     reset_from_domain(c, S);
     if (is_static && c.lane == 1) c.obs = 0.0f;   // reset(static=True): row 0 carries 0 instead of the area ratio (C:1213-1218)
-    if (nv_count && c.lane == 0) nv_count[env] = 0;  // self.not_valid_points = [], B:73
+    if (nv_count && c.lane == 0) {
+        nv_count[env] = 0;                    // self.not_valid_points = [], B:73
+        nv_meta[(size_t)env * kNvMeta] += 1;  // a new episode: its generated vertices are new objects (last_not_valid_points, B:416)
+    }
     if (c.lane == 0) {
         EnvCounters z;
         if (first) {
@@ -1714,7 +1719,7 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
 
 // ------------------------------------------------------------------------------------------ move() API
 
-enum { kMoveOk = 0, kMoveNone = 1, kMoveRaises = 2, kMoveNeedsSmoothing = 3 };
+enum { kMoveOk = 0, kMoveNone = 1, kMoveRaises = 2, kMoveNeedsSmoothing = 3, kMoveSmoothRaises = 4 };
 
 __host__ __device__ __forceinline__ size_t move_lds_bytes(int cap) { return lds_bytes_for(cap) + sizeof(double2) * (size_t)cap; }
 
@@ -1729,7 +1734,7 @@ __global__ void __launch_bounds__(64) k_move(DevState S, int cap, const double *
                                               const double *__restrict__ types, float *__restrict__ obs_out,
                                               uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
                                               uint8_t *__restrict__ code, double2 *__restrict__ nv_xy,
-                                              int32_t *__restrict__ nv_count)
+                                              int32_t *__restrict__ nv_count, int32_t *__restrict__ nv_gid)
 {
     extern __shared__ double2 smem[];
     Ctx c;
@@ -1750,6 +1755,7 @@ __global__ void __launch_bounds__(64) k_move(DevState S, int cap, const double *
     for (int k = lane; k < n_nv; k += 64) nv[k] = gnv[k];
     wave_sync();
     const double2 refpt = c.xy[c.ref];  // the reference vertex of this move, before any update
+    const int refgid = c.id[c.ref];     // ... and its identity (the reference's list holds Vertex objects)
     Decision d = env_check(c, S, 0.0f, 0.0f, 0.0f, false, true, mv_r, mv_a, mv_type);
     if (d.ok) {
         env_apply(c, S, d, nullptr, true, nv, n_nv);  // B:345: the selection still sees the old not_valid_points
@@ -1762,6 +1768,7 @@ __global__ void __launch_bounds__(64) k_move(DevState S, int cap, const double *
             if (lane == 0) {
                 nv[n_nv] = refpt;
                 gnv[n_nv] = refpt;
+                nv_gid[(size_t)env * cap + n_nv] = refgid;
             }
             n_nv += 1;
         }

@@ -902,4 +902,48 @@ k_apply_reselect(DevState S, Reselect *__restrict__ pend, const float *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------ move() through smooth_pave
+//
+// rl/boundary_env.py:405-426: when move() finds no selectable reference vertex on a front of more than 4 vertices it runs
+// smooth_pave (front + interior smoothing, candidate rebuild), ends the episode if not_valid_points repeats the list of the
+// previous smoothing (first entry, last entry, length; last_not_valid_points is set only here and survives reset()),
+// empties the list and selects again (static observation); no reference vertex even then ends the episode.  k_move marks
+// such envs kMoveNeedsSmoothing; meshenv_move then runs the smoothing kernels under this mask and k_move_finish.
+
+__global__ void k_move_mask(const uint8_t *__restrict__ code, uint8_t *__restrict__ mask, int n)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) mask[e] = code[e] == (uint8_t)kMoveNeedsSmoothing ? 1 : 0;
+}
+
+__global__ void k_move_finish(DevState S, int cap, const uint8_t *__restrict__ mask, const int32_t *__restrict__ sweeps,
+                              int32_t *__restrict__ nv_count, const int32_t *__restrict__ nv_gid, int32_t *__restrict__ nv_meta,
+                              uint8_t *__restrict__ done, uint8_t *__restrict__ complete, uint8_t *__restrict__ code)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S.n_envs || mask[e] == 0) return;
+    const int sw = sweeps[e];
+    if (sw == kSmoothRaises) {   // the reference raises out of move(): the caller resets
+        code[e] = (uint8_t)kMoveSmoothRaises;
+        done[e] = 1;
+        return;
+    }
+    if (sw < 0) return;          // graph not rebuildable (log overflow): stays kMoveNeedsSmoothing, done = 1
+    int32_t *m = nv_meta + (size_t)e * kNvMeta;
+    const int cnt = nv_count[e], epoch = m[0];
+    const int first = cnt > 0 ? nv_gid[(size_t)e * cap] : 0, last = cnt > 0 ? nv_gid[(size_t)e * cap + cnt - 1] : 0;
+    bool dn = false;
+    if (m[3] > 0 && cnt > 0) {
+        const bool same_f = first == m[1] && ((first & kNewBit) == 0 || m[4] == epoch);
+        const bool same_l = last == m[2] && ((last & kNewBit) == 0 || m[4] == epoch);
+        dn = same_f && same_l && cnt == m[3];
+    }
+    m[1] = first; m[2] = last; m[3] = cnt; m[4] = epoch;   // self.last_not_valid_points = self.not_valid_points
+    nv_count[e] = 0;                                        // self.not_valid_points = []
+    const bool none = (S.scal[e].status & kStNoReference) != 0;   // the selection k_rebuild_candidates<2> just made
+    done[e] = (uint8_t)((dn || none) ? 1 : 0);
+    complete[e] = 0;
+    code[e] = (uint8_t)(none ? kMoveNone : kMoveOk);
+}
+
 }  // namespace meshenv

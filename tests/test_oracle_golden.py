@@ -71,11 +71,12 @@ from conftest import move_golden_names  # noqa: E402
 
 def replay_move(tr, make_env, do_reset, do_move, state_of, obs_cmp=np.testing.assert_array_equal):
     """Shared by the oracle test (here) and the GPU test: replays a recorded move() trace through `do_move` and compares
-    with what the reference returned.  codes: 0 ok, 1 obs None, 2 the reference raises, 3 it would smooth."""
+    with what the reference returned.  codes: 0 ok, 1 obs None, 2 the reference raises UnboundLocalError (ring <= 5),
+    4 it raises inside smooth_pave; calls that went through smooth_pave (B:405-426) are ordinary calls here."""
     env = make_env(tr)
     obs = do_reset(env)
     obs_cmp(obs, tr["reset_obs"])
-    seen = np.zeros(4, int)
+    seen = np.zeros(5, int)
     for t in range(len(tr["points"])):
         obs, done, comp, code = do_move(env, tr["points"][t], float(tr["types"][t]))
         assert code == tr["code"][t], (t, code, tr["code"][t])
@@ -115,8 +116,11 @@ def test_oracle_move_matches_reference_trace(name):
 
 def test_move_golden_covers_every_return_path():
     trs = [dict(np.load(os.path.join(GOLDEN_DIR, n + ".npz"))) for n in move_golden_names()]
-    codes = np.sum([np.bincount(t["code"], minlength=4) for t in trs], axis=0)
-    assert (codes > 0).all(), codes                 # ok / None observation / raises / needs smoothing
+    codes = np.sum([np.bincount(t["code"], minlength=5) for t in trs], axis=0)
+    assert codes[0] > 0 and codes[2] > 0, codes     # ok / the reference raises on a finished ring
+    smoothed = sum(int(t["smoothed"].sum()) for t in trs)
+    assert smoothed >= 30                            # move() went through smooth_pave (B:405-426) ...
+    assert any(((t["smoothed"] == 1) & (t["done"] == 1)).any() for t in trs)   # ... and ended an episode there (B:416-420)
     assert any(((t["done"] == 1) & (t["complete"] == 1)).any() for t in trs)      # ring of 4: complete
     assert any(((t["done"] == 1) & (t["complete"] == 0) & (t["code"] == 0)).any() for t in trs)  # ring of 5
     assert any((t["n_not_valid"] > 8).any() for t in trs)
