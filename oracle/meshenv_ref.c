@@ -897,7 +897,7 @@ int meshenv_ref_move(RefEnv *e, const double *point, double type, float *obs, ui
         if (none) { /* B:405-426: smooth_pave, then a fresh selection with an empty not_valid_points */
             int32_t sweeps = 0;
             int src = meshenv_ref_smooth_front(e);
-            if (src == -3) { *done_out = (uint8_t)done; *complete_out = 0; return MESHENV_REF_MOVE_SMOOTH_RAISES; }
+            if (src == -3) { *done_out = 1; *complete_out = 0; return MESHENV_REF_MOVE_SMOOTH_RAISES; } /* the caller resets */
             if (src == 0) src = meshenv_ref_smooth_interior(e, 400, &sweeps, NULL);
             if (src != 0) { /* log overflow: the graph cannot be rebuilt -- the episode ends here (not a reference path) */
                 *done_out = 1; *complete_out = 0;

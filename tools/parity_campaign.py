@@ -45,14 +45,16 @@ def campaign(label, doms, env_domain, T, seed, biased, threads=16):
     env.close()
 
 def move_campaign(label, doms, env_domain, T, seed):
-    """move() API (rl/boundary_env.py:265-432) in lockstep with the oracle's meshenv_ref_move."""
+    """move() API (rl/boundary_env.py:265-432) in lockstep with the oracle's meshenv_ref_move, including the moves that
+    go through smooth_pave (:405-426)."""
     n = len(env_domain)
-    env = MeshVecEnv(doms, env_domain=env_domain, auto_reset=False)
-    refs = [RefEnv.from_points(doms[d], cap_new=64) for d in env_domain]
+    env = MeshVecEnv(doms, env_domain=env_domain, auto_reset=False, log_capacity=512)
+    refs = [RefEnv.from_points(doms[d], cap_new=512) for d in env_domain]
     obs = env.reset(static=True).cpu().numpy()
     assert np.array_equal(obs, np.stack([r.reset(static=True)[0] for r in refs]))
     rng = np.random.default_rng(seed)
-    st = dict(moves=0, codes=[0, 0, 0, 0], valid=0, obs_mis=0, max_obs=0.0, flag_mis=0, topo_checked=0, topo_bad=0)
+    st = dict(moves=0, codes=[0, 0, 0, 0, 0], smoothed=0, valid=0, obs_mis=0, obs_mis_moves=0, obs_mis_domains=set(), max_obs=0.0, flag_mis=0, topo_checked=0, topo_bad=0,
+              max_ring_dev=0.0)
     t0 = time.time()
     for t in range(T):
         pts = np.stack([rng.uniform(0.05, 0.45, n), rng.uniform(0.2, 1.5, n)], axis=1)
@@ -61,12 +63,20 @@ def move_campaign(label, doms, env_domain, T, seed):
         mask = np.zeros(n, np.uint8)
         for k in range(n):
             ne0 = refs[k].scalars()["n_elem"]
+            nv0 = refs[k].not_valid_count()
             o_r, d_r, c_r, code_r = refs[k].move(pts[k], typ[k])
+            st["smoothed"] += int(code_r != 2 and refs[k].scalars()["n_elem"] == ne0 and refs[k].not_valid_count() == 0 and nv0 > 0)
             st["codes"][code_r] += 1
             bad = int(code[k] != code_r) + (int(bool(d[k]) != d_r) + int(bool(c[k]) != c_r) if code_r != 2 else 0)
             st["flag_mis"] += bad
+            if bad:
+                print(f"  flag mismatch: step {t} env {k} domain {int(env_domain[k])} code {int(code[k])}/{code_r} done {int(d[k])}/{int(d_r)} "
+                      f"complete {int(c[k])}/{int(c_r)} front {len(refs[k].ring()[0])} not_valid before {nv0}", flush=True)
             if code_r == 0:
                 st["obs_mis"] += int((o[k] != o_r).sum())
+                if (o[k] != o_r).any():
+                    st["obs_mis_moves"] += 1
+                    st["obs_mis_domains"].add(int(env_domain[k]))
                 st["max_obs"] = max(st["max_obs"], float(np.abs(o[k].astype(np.float64) - o_r).max()))
             st["valid"] += refs[k].scalars()["n_elem"] > ne0
             if d_r or code_r >= 2:
@@ -79,16 +89,23 @@ def move_campaign(label, doms, env_domain, T, seed):
             for k in rng.choice(n, size=min(96, n), replace=False):
                 s = env.get_state(int(k)); ids, xy = refs[k].ring()
                 st["topo_checked"] += 1
-                if not (np.array_equal(s["ring_ids"], ids) and np.array_equal(s["ring_xy"], xy)
+                dev = float(np.abs(s["ring_xy"] - xy).max()) if len(ids) == len(s["ring_ids"]) else 1.0
+                st["max_ring_dev"] = max(st["max_ring_dev"], dev)   # exact until a smoothing moved the front (tan / cos / sqrt)
+                if not (np.array_equal(s["ring_ids"], ids) and dev <= 1e-10
                         and len(env.get_not_valid(int(k))) == refs[k].not_valid_count()):
                     st["topo_bad"] += 1
     st["seconds"] = round(time.time() - t0, 1)
+    st["obs_mis_domains"] = sorted(st["obs_mis_domains"])
     print(label, st, flush=True)
     env.close()
 
 
 if __name__ == "__main__":
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+    if "--move-only" in sys.argv:
+        mdoms = [boundary(0), boundary(-1), boundary(1), boundary(2)] + [golden_domain(x) for x in ("boundary16_biased_s2", "random1_1_biased_s1", "star_biased_s6")] + [random_domain(7000 + k) for k in range(25)]
+        move_campaign("move() x2048 on 32 domains", mdoms, (np.arange(2048) % len(mdoms)).astype(np.int32), int(60 * scale), 105)
+        sys.exit(0)
     campaign("boundary0 x4096 uniform", [boundary(0)], np.zeros(4096, np.int32), int(1000 * scale), 101, False)
     campaign("boundary0 x4096 biased", [boundary(0)], np.zeros(4096, np.int32), int(1000 * scale), 102, True)
     big = [golden_domain(x) for x in ("boundary16_biased_s2", "boundary15_biased_s5", "test1_biased_s42", "dolphine3_biased_s0", "random1_1_biased_s1", "star_biased_s6")]
@@ -96,4 +113,5 @@ if __name__ == "__main__":
     rnd = [random_domain(5000 + k) for k in range(1024)]
     campaign("1024 random polygons x4096 biased", rnd, (np.arange(4096) % 1024).astype(np.int32), int(400 * scale), 104, True)
     mdoms = [boundary(0), boundary(-1), boundary(1), boundary(2)] + big + [random_domain(7000 + k) for k in range(22)]
-    move_campaign("move() x2048 on 32 domains", mdoms, (np.arange(2048) % len(mdoms)).astype(np.int32), int(60 * scale), 105)
+    if "--no-move" not in sys.argv:
+        move_campaign("move() x2048 on 32 domains", mdoms, (np.arange(2048) % len(mdoms)).astype(np.int32), int(60 * scale), 105)
