@@ -132,6 +132,14 @@ class BoudaryEnv:  # the reference's spelling
             raise RuntimeError(f"smooth(): not applicable to this episode (code {n}: see _capi.SMOOTH_*)")
         return n
 
+    def extract_samples_2(self, meshes=None, n_neighbor=2, n_radius=3, radius=4, index=1, quality_threshold=0.7):
+        """MeshGeneration.extract_samples_2, general/mesh.py:1438-1489, on this env's generated mesh (`meshes` is implied:
+        the elements of the running episode).  Host-side like the reference's; see samples.py."""
+        from .samples import extract_samples_2
+        quads, vxy = self._vec.get_elements(0)
+        return extract_samples_2(quads, vxy, len(self.points), n_neighbor, n_radius, radius, index=index,
+                                 quality_threshold=quality_threshold)
+
     @property
     def not_valid_points(self):
         """[k, 2] coordinates of the reference vertices rejected since the last valid move (rl/boundary_env.py:47)."""

@@ -127,3 +127,21 @@ def test_single_env_move_and_static_reset_follow_the_reference_surface():
             env.reset(static=True)
     assert raised > 0
     env.close()
+
+
+def test_extract_samples_2_from_the_device_mesh_equals_the_reference():
+    """general/mesh.py:1438-1489 on the mesh the DEVICE generated from the recorded actions: the reference's own
+    (all_samples, types, outputs), value for value -- element log, vertex table and neighbour order all line up."""
+    from reinforcementlearning4meshgeneration_amd import BoudaryEnv
+    for name in ("samples_boundary0_post", "samples_star_ebrd"):
+        tr = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        env = BoudaryEnv([tuple(p) for p in tr["vertex_xy"][:int(tr["n0"])]])
+        env.reset()
+        for a in tr["actions"]:
+            env.step(a)
+        nn, nr, rad, idx, thr = tr["params"]
+        samples, types, outputs = env.extract_samples_2(None, int(nn), int(nr), rad, index=int(idx), quality_threshold=float(thr))
+        assert np.array_equal(np.array(samples, np.float64), tr["samples"])
+        assert np.array_equal(np.array(types, np.float64).reshape(-1), tr["types"])
+        assert np.array_equal(np.array(outputs, np.float64), tr["outputs"])
+        env.close()
