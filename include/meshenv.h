@@ -261,6 +261,12 @@ int meshenv_smooth_final(MeshEnv *h, const uint8_t *mask_dev, int iteration, dou
 /* Host-side readout of one env's not_valid_points (synchronises the stream): xy_host[2*cap_points], *count = length. */
 int meshenv_get_not_valid(MeshEnv *h, int env, double *xy_host, int cap_points, int32_t *count);
 
+/* The same list as vertex ids (the reference's list holds Vertex objects: identity), and the summary of
+ * last_not_valid_points (rl/boundary_env.py:48,416-422: set where move() smooths, compared by first entry, last entry and
+ * length, never cleared by reset()): last_host[4] = first id, last id, length, 1 if it was recorded in the running
+ * episode (a generated vertex of an earlier episode is a different object).  ids_host / last_host nullable. */
+int meshenv_get_not_valid_ids(MeshEnv *h, int env, int32_t *ids_host, int cap_ids, int32_t *count, int32_t *last_host);
+
 /*
  * Multi-GPU exchange message.  With msg_dev != NULL every following meshenv_step / meshenv_rollout also writes
  * msg_dev[n_envs*21] float32 = (obs[18] | reward | done | complete) per env -- the buffer a rank hands to

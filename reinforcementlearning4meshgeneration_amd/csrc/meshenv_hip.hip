@@ -693,6 +693,38 @@ int meshenv_get_not_valid(MeshEnv *h, int env, double *xy_host, int cap_points, 
     return MESHENV_OK;
 }
 
+int meshenv_get_not_valid_ids(MeshEnv *h, int env, int32_t *ids_host, int cap_ids, int32_t *count, int32_t *last_host)
+{
+    if (!h || !count) return MESHENV_E_ARG;
+    if (env < 0 || env >= h->n_envs) {
+        h->err = "meshenv_get_not_valid_ids: env out of range";
+        return MESHENV_E_RANGE;
+    }
+    *count = 0;
+    if (last_host) last_host[0] = last_host[1] = last_host[2] = last_host[3] = 0;
+    if (!h->nv_xy) return MESHENV_OK;  // move() never called
+    MESHENV_ON_DEVICE(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int32_t n = 0, meta[kNvMeta];
+    HIP_TRY(h, hipMemcpy(&n, h->nv_count + env, sizeof(n), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(meta, h->nv_meta + (size_t)env * kNvMeta, sizeof(meta), hipMemcpyDeviceToHost));
+    EnvScalars s;
+    HIP_TRY(h, hipMemcpy(&s, h->S.scal + env, sizeof(s), hipMemcpyDeviceToHost));
+    const int n0 = h->dom_off_host[s.dom + 1] - h->dom_off_host[s.dom];
+    auto gid = [n0](int32_t g) { return (g & kNewBit) ? n0 + (g & ~kNewBit) : g; };
+    *count = n;
+    if (ids_host && n > 0) {
+        const int m = n < cap_ids ? n : cap_ids;
+        HIP_TRY(h, hipMemcpy(ids_host, h->nv_gid + (size_t)env * h->cap, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; i++) ids_host[i] = gid(ids_host[i]);
+    }
+    if (last_host) {
+        last_host[0] = gid(meta[1]); last_host[1] = gid(meta[2]); last_host[2] = meta[3];
+        last_host[3] = meta[4] == meta[0] ? 1 : 0;
+    }
+    return MESHENV_OK;
+}
+
 static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float *obs_dev, double *reward_dev,
                        uint8_t *done_dev, uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset)
 {

@@ -332,6 +332,16 @@ class MeshVecEnv:
                     "meshenv_get_not_valid")
         return xy[:2 * n.value].reshape(-1, 2).copy()
 
+    def get_not_valid_ids(self, env: int):
+        """(ids of not_valid_points, (first id, last id, length, same_episode) of last_not_valid_points) of one env."""
+        cap = self.max_ring
+        ids = np.zeros(cap, np.int32)
+        last = np.zeros(4, np.int32)
+        n = C.c_int32(0)
+        self._check(self._L.meshenv_get_not_valid_ids(self._handle, int(env), ids.ctypes.data, cap, C.byref(n),
+                                                      last.ctypes.data), "meshenv_get_not_valid_ids")
+        return ids[:n.value].copy(), tuple(int(x) for x in last)
+
     def step(self, actions):
         """One step() of every env.  actions: float32 CUDA tensor [n, 3].
         Returns (obs, reward, done, complete) -- views of buffers that the next call overwrites."""
