@@ -53,6 +53,22 @@ for k in range(0, shadow, 16):
 print(f"oracle (1 thread): {dt / shadow * 1e6:.1f} us/env -> {dt / shadow * n * 1e3:.1f} ms for {n} envs; device/oracle speed "
       f"{dt / shadow * n * 1e3 / ms:.0f}x; shadowed vertex tables bit-identical")
 
+# ---- the full smooth_pave (front smoother + interior + rebuild + find_next_state) on a second, identically stepped batch
+env2 = MeshVecEnv([dom], n_envs=n, auto_reset=False, log_capacity=cap)
+env2.reset()
+rng2 = np.random.default_rng(3)
+for t in range(T):
+    a = rng2.uniform([-1, 0.2, 0.3], [1, 1.0, 1.2], size=(n, 3)).astype(np.float32)
+    env2.step(torch.from_numpy(a).cuda())
+env2.smooth_pave(iteration=0, interior=True)
+torch.cuda.synchronize()
+e0.record()
+sweeps2, _ = env2.smooth_pave(iteration=400, interior=False)
+e1.record(); torch.cuda.synchronize()
+print(f"smooth_pave(interior=False): {e0.elapsed_time(e1):.3f} ms for {n} envs, sweeps mean {float(sweeps2.float().mean()):.1f}, "
+      f"refused / raised {int((sweeps2 < 0).sum())}")
+env2.close()
+
 # ---- finished meshes: meshenv_smooth_final (MeshGeneration.smooth), on the 13-vertex odd ring of the fixtures
 tr = np.load(os.path.join(ROOT, "tests", "golden", "smoothfinal_ring13_s4.npz"))
 dom = [tuple(p) for p in tr["domain_xy"]]
