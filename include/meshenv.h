@@ -248,15 +248,19 @@ int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int inter
                    double *diff_dev, float *obs_dev);
 
 /* MeshGeneration.smooth(boundary.vertices, lr_1, lr_2, iteration), general/mesh.py:1290-1392 -- the post-processing of a
- * FINISHED mesh (general/EBRD.py:391: front of <= 5 vertices) -- on every env with mask_dev[e] != 0 whose running episode
- * has ended and has not been reset (step with auto_reset = 0, smooth, read the mesh, reset): every generated vertex, front
- * vertices included, by the number of elements around it -- 4th-vertex estimates for 1 and 2 (general/mesh.py:1305-1361),
- * the Laplacian step otherwise -- until the coordinate sum of the whole vertex list changes by <= 0.001 or `iteration`
- * sweeps.  The reference's defaults are lr_1 = lr_2 = 0.999, iteration = 400.  The vertex log and the front's coordinates
- * hold the result; the candidate list of the (finished) episode is not rebuilt -- the next call on such an env is a reset.
- * sweeps_dev / diff_dev as meshenv_smooth, plus MESHENV_SMOOTH_NOT_FINISHED and MESHENV_SMOOTH_INDEX_ERROR (env untouched). */
-int meshenv_smooth_final(MeshEnv *h, const uint8_t *mask_dev, int iteration, double lr_1, double lr_2, int32_t *sweeps_dev,
-                         double *diff_dev);
+ * FINISHED mesh (general/EBRD.py:391: front of <= 5 vertices) -- on every env with mask_dev[e] != 0:
+ *   which = 0: the running episode, ended complete and not reset yet (step with auto_reset = 0, smooth, read, reset);
+ *   which = 1: the archived episode (what meshenv_get_last_episode reads: the finished mesh auto-reset left behind); its
+ *              front, of which smooth() only needs the membership, is recovered from the logs (the vertices on edges used
+ *              an odd number of times by domain ring + elements; a front of 4 closed by the last element = that element).
+ * Every generated vertex, front vertices included, by the number of elements around it -- 4th-vertex estimates for 1 and 2
+ * (general/mesh.py:1305-1361), the Laplacian step otherwise -- until the coordinate sum of the whole vertex list changes by
+ * <= 0.001 or `iteration` sweeps.  The reference's defaults are lr_1 = lr_2 = 0.999, iteration = 400.  The vertex log (and,
+ * for which = 0, the front's coordinates) hold the result; the candidate list of the finished episode is not rebuilt -- the
+ * next call on such an env is a reset.  sweeps_dev / diff_dev as meshenv_smooth, plus MESHENV_SMOOTH_NOT_FINISHED (front
+ * > 5, nothing archived, archived episode truncated) and MESHENV_SMOOTH_INDEX_ERROR (env untouched). */
+int meshenv_smooth_final(MeshEnv *h, int which, const uint8_t *mask_dev, int iteration, double lr_1, double lr_2,
+                         int32_t *sweeps_dev, double *diff_dev);
 
 /* Host-side readout of one env's not_valid_points (synchronises the stream): xy_host[2*cap_points], *count = length. */
 int meshenv_get_not_valid(MeshEnv *h, int env, double *xy_host, int cap_points, int32_t *count);

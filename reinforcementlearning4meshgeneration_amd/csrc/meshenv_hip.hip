@@ -648,10 +648,10 @@ int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int inter
     return MESHENV_OK;
 }
 
-int meshenv_smooth_final(MeshEnv *h, const uint8_t *mask_dev, int iteration, double lr_1, double lr_2, int32_t *sweeps_dev,
-                         double *diff_dev)
+int meshenv_smooth_final(MeshEnv *h, int which, const uint8_t *mask_dev, int iteration, double lr_1, double lr_2,
+                         int32_t *sweeps_dev, double *diff_dev)
 {
-    if (!h) return MESHENV_E_ARG;
+    if (!h || (which != 0 && which != 1)) return MESHENV_E_ARG;
     if (iteration < 0) return fail_arg(h, "meshenv_smooth_final: iteration must be >= 0");
     const int log_cap = h->S.prm.log_cap;
     if (log_cap <= 0) {
@@ -666,8 +666,8 @@ int meshenv_smooth_final(MeshEnv *h, const uint8_t *mask_dev, int iteration, dou
         HIP_TRY(h, hipFuncSetAttribute((const void *)k_smooth_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         h->smooth_final_ready = true;
     }
-    hipLaunchKernelGGL(k_smooth_final, dim3(h->n_envs), dim3(64), lds, h->stream, h->S, h->cap, mask_dev, iteration, lr_1, lr_2,
-                       sweeps_dev, diff_dev);
+    hipLaunchKernelGGL(k_smooth_final, dim3(h->n_envs), dim3(64), lds, h->stream, h->S, h->cap, which, mask_dev, iteration, lr_1,
+                       lr_2, sweeps_dev, diff_dev);
     HIP_TRY(h, hipGetLastError());
     return MESHENV_OK;
 }

@@ -42,10 +42,14 @@ __host__ __device__ __forceinline__ size_t smooth_lds_bytes(int ring_cap, int lo
 // Vertex.segments as neighbour lists, for the vertices first .. first + count - 1 (unified index: domain vertex i -> i,
 // k-th generated vertex -> n0 + k), one lane per vertex, every lane scanning the element log in order (all lanes read
 // the same 16-byte record).  Row r = vertex first + r: adj[r][0 .. deg[r]), n_mesh[r] (nullable) = elements that contain
-// it.  A domain vertex starts with its two ring segments in the order general/mesh.py:1926-1930 creates them.  Returns
-// true (per lane) when a vertex has more than kSmoothMaxDeg neighbours.
+// it.  A domain vertex starts with its two ring segments in the order general/mesh.py:1926-1930 creates them.  on_hole[r]
+// (nullable) = 1 when the vertex has an edge that is used an odd number of times by (domain ring + elements): such edges
+// bound what is not meshed yet, i.e. their vertices ARE the current front -- which makes the front recoverable from the
+// logs of an archived episode, whose ring has been reset.  Returns true (per lane) when a vertex has more than
+// kSmoothMaxDeg neighbours.
 __device__ __forceinline__ bool build_segment_lists(const int4 *__restrict__ quads, int n_elem, int n0, int first, int count,
-                                                    unsigned short *adj, unsigned char *deg, unsigned char *n_mesh)
+                                                    unsigned short *adj, unsigned char *deg, unsigned char *n_mesh,
+                                                    unsigned char *on_hole = nullptr)
 {
     const int lane = lane_id();
     bool too_many = false;
@@ -53,12 +57,14 @@ __device__ __forceinline__ bool build_segment_lists(const int4 *__restrict__ qua
         const int r = r0 + lane, u_me = first + r;
         const int me = u_me >= n0 ? (kNewBit | (u_me - n0)) : u_me;
         unsigned short mine[kSmoothMaxDeg] = {};
+        unsigned long long uses = 0ULL;   // 4-bit use count per neighbour slot
         int d = 0, nm = 0;
         if (u_me < n0) {  // for i in range(n0): Segment(v[i-1], v[i]) is appended to v[i-1], then to v[i]
             const int prev = u_me == 0 ? n0 - 1 : u_me - 1, next = u_me == n0 - 1 ? 0 : u_me + 1;
             mine[0] = (unsigned short)(u_me == n0 - 1 ? next : prev);
             mine[1] = (unsigned short)(u_me == n0 - 1 ? prev : next);
             d = 2;
+            uses = 0x11ULL;
         }
         for (int e = 0; e < n_elem; e++) {
             const int4 q = quads[e];
@@ -72,19 +78,21 @@ __device__ __forceinline__ bool build_segment_lists(const int4 *__restrict__ qua
             for (int s = 0; s < 2; s++) {
                 const int g = s == 0 ? first_g : second_g;
                 const unsigned short u = (unsigned short)((g & kNewBit) ? n0 + (g & ~kNewBit) : g);
-                bool have = false;
+                int at = -1;
 #pragma unroll
-                for (int j = 0; j < kSmoothMaxDeg; j++) have = have || (j < d && mine[j] == u);
-                if (!have) {
+                for (int j = 0; j < kSmoothMaxDeg; j++) at = (at < 0 && j < d && mine[j] == u) ? j : at;
+                if (at < 0) {
                     if (d < kSmoothMaxDeg) {
 #pragma unroll
                         for (int j = 0; j < kSmoothMaxDeg; j++)
                             if (j == d) mine[j] = u;
+                        at = d;
                         d += 1;
                     } else {
                         too_many = true;
                     }
                 }
+                if (at >= 0) uses += 1ULL << (4 * at);
             }
         }
         if (r < count) {
@@ -92,6 +100,7 @@ __device__ __forceinline__ bool build_segment_lists(const int4 *__restrict__ qua
             for (int j = 0; j < kSmoothMaxDeg; j++) adj[(size_t)r * kSmoothMaxDeg + j] = mine[j];
             deg[r] = (unsigned char)d;
             if (n_mesh) n_mesh[r] = (unsigned char)(nm > 255 ? 255 : nm);
+            if (on_hole) on_hole[r] = (uses & 0x1111111111111111ULL) != 0ULL ? 1 : 0;
         }
     }
     return too_many;
@@ -288,11 +297,14 @@ __device__ __forceinline__ double2 estimate_4th_vertex(double2 origin, double2 l
     return make_double2(r1x + distance * sc.c, r1y + distance * sc.s);
 }
 
-// One wavefront per env whose episode has ended (front <= 5, not yet reset: step with auto_reset = 0).  Codes as
-// k_smooth_interior plus kSmoothNotFinished (front > 5: untouched) and kSmoothIndexError (the reference raises
-// IndexError at M:1311 / 1344 / 1348 on an empty common-neighbour list: untouched).
+// One wavefront per env whose episode has ended complete (front <= 5).  which = 0: the running episode, not yet reset
+// (step with auto_reset = 0); which = 1: the archived episode (the other half of the logs: what auto-reset left behind;
+// its front -- smooth() only asks which vertices are on it and how far they are -- is recovered from the logs, see
+// build_segment_lists).  Codes as k_smooth_interior plus kSmoothNotFinished (front > 5 / nothing archived / archived
+// episode truncated: untouched) and kSmoothIndexError (the reference raises IndexError at M:1311 / 1344 / 1348 on an
+// empty common-neighbour list: untouched).
 __global__ void __launch_bounds__(64)
-k_smooth_final(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int iteration, double lr_1, double lr_2,
+k_smooth_final(DevState S, int ring_cap, int which, const uint8_t *__restrict__ mask, int iteration, double lr_1, double lr_2,
                int32_t *__restrict__ sweeps_out, double *__restrict__ diff_out)
 {
     extern __shared__ double2 smem[];
@@ -304,15 +316,25 @@ k_smooth_final(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int i
     const int log_cap = S.prm.log_cap;
     const EnvScalars sc = S.scal[env];
     const DevCold cold = load_cold(S);
-    const int n = uniform_i32(sc.n), n_elem = uniform_i32(sc.n_elem), n_new = uniform_i32(sc.n_new);
+    int n = uniform_i32(sc.n), n_elem = uniform_i32(sc.n_elem), n_new = uniform_i32(sc.n_new);
     const int status = uniform_i32(sc.status);
-    if ((status & kStLogOverflow) || n_elem > log_cap || n_new > log_cap || n > 5) {
-        if (lane == 0 && sweeps_out) sweeps_out[env] = n > 5 ? kSmoothNotFinished : kSmoothLogOverflow;
+    bool overflow = (status & kStLogOverflow) != 0, finished = n <= 5;
+    int half = (status >> 4) & 1;
+    if (which) {
+        const LastEpisode le = cold.last_ep[env];
+        n_elem = uniform_i32(le.n_elem); n_new = uniform_i32(le.n_new);
+        overflow = (uniform_i32(le.flags) & 2) != 0;
+        finished = uniform_i32(le.episodes) > 0 && (uniform_i32(le.flags) & 1) != 0;
+        half ^= 1;
+        n = 0;   // the front comes from the logs
+    }
+    if (overflow || n_elem > log_cap || n_new > log_cap || !finished) {
+        if (lane == 0 && sweeps_out) sweeps_out[env] = !finished ? kSmoothNotFinished : kSmoothLogOverflow;
         return;
     }
     const DomConst dc = S.dom[uniform_i32(sc.dom)];
     const int doff = uniform_i32(dc.off), n0 = uniform_i32(dc.n0), nv = n0 + n_new;
-    const size_t lbase = ((size_t)env * 2 + ((status >> 4) & 1)) * log_cap;
+    const size_t lbase = ((size_t)env * 2 + half) * log_cap;
     const int4 *quads = reinterpret_cast<const int4 *>(cold.log_quads + lbase * 4);
     double2 *vnew = cold.log_vxy + lbase;
 
@@ -335,12 +357,40 @@ k_smooth_final(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int i
         ringu[i] = (unsigned short)u;
         front[u] = 1;
     }
-    const bool too_many = build_segment_lists(quads, n_elem, n0, 0, nv, adj, deg, n_mesh);
+    const bool too_many = build_segment_lists(quads, n_elem, n0, 0, nv, adj, deg, n_mesh, which ? front : nullptr);
     if (__ballot(too_many) != 0ULL) {
         if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothDegree;
         return;
     }
     wave_sync();
+    if (which) {
+        // the front of the archived episode: the vertices on edges used an odd number of times; none left (a front of 4
+        // was closed by the last element, B:235-238) -> that element's four vertices
+        int cnt = 0;
+        for (int u0 = 0; u0 < nv; u0 += 64) {
+            const int u = u0 + lane;
+            const bool f = u < nv && front[u] != 0;
+            const unsigned long long m = __ballot(f);
+            if (f) {
+                const int pos = cnt + __popcll(m & ((1ULL << lane) - 1ULL));
+                if (pos < ring_cap) ringu[pos] = (unsigned short)u;
+            }
+            cnt += __popcll(m);
+        }
+        if (cnt == 0 && n_elem > 0) {
+            const int4 q = quads[n_elem - 1];
+            const int gq[4] = {q.x, q.y, q.z, q.w};
+            if (lane < 4) {
+                const int gg = lane == 0 ? gq[0] : (lane == 1 ? gq[1] : (lane == 2 ? gq[2] : gq[3]));
+                const int u = (gg & kNewBit) ? n0 + (gg & ~kNewBit) : gg;
+                ringu[lane] = (unsigned short)u;
+                front[u] = 1;
+            }
+            cnt = 4;
+        }
+        n = cnt < ring_cap ? cnt : ring_cap;
+        wave_sync();
+    }
     SmoothGraph g;
     g.coord = coord; g.adj = adj; g.deg = deg;
     // the stop rule's sum runs over the domain ring first: that prefix never changes
@@ -446,11 +496,13 @@ k_smooth_final(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int i
         return;
     }
     for (int k = lane; k < n_new; k += 64) vnew[k] = coord[n0 + k];
-    // front vertices moved with the rest: the ring arrays hold copies of their coordinates
-    double2 *rxy = S.ring_xy + (size_t)env * S.cap;
-    for (int i = lane; i < n; i += 64) rxy[i] = coord[ringu[i]];
+    if (!which) {
+        // front vertices moved with the rest: the ring arrays hold copies of their coordinates
+        double2 *rxy = S.ring_xy + (size_t)env * S.cap;
+        for (int i = lane; i < n; i += 64) rxy[i] = coord[ringu[i]];
+        if (lane == 0) S.scal[env].status = status & ~(kStRm1Bad | kStRp1Bad);
+    }
     if (lane == 0) {
-        S.scal[env].status = status & ~(kStRm1Bad | kStRp1Bad);
         if (sweeps_out) sweeps_out[env] = it;
         if (diff_out) diff_out[env] = diffs;
     }

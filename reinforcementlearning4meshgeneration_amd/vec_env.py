@@ -301,11 +301,14 @@ class MeshVecEnv:
         self._check(rc, "meshenv_smooth")
         return self.smooth_sweeps, self.smooth_diff
 
-    def smooth(self, mask=None, lr_1: float = 0.999, lr_2: float = 0.999, iteration: int = 400):
-        """MeshGeneration.smooth(boundary.vertices, lr_1, lr_2, iteration) (general/mesh.py:1290-1392) on the FINISHED
-        running episodes (front <= 5, not reset yet: create the env with auto_reset=False): all generated vertices are
-        relaxed, front included.  Returns (sweeps int32 [n], diff float64 [n]); sweeps < 0: _capi.SMOOTH_* (env untouched,
-        e.g. SMOOTH_NOT_FINISHED for an episode that is still running)."""
+    def smooth(self, mask=None, lr_1: float = 0.999, lr_2: float = 0.999, iteration: int = 400, which: str = "current"):
+        """MeshGeneration.smooth(boundary.vertices, lr_1, lr_2, iteration) (general/mesh.py:1290-1392) on FINISHED
+        meshes: which="current" -- running episodes that ended complete and were not reset yet (auto_reset=False);
+        which="last" -- the archived episode of every env (what get_last_episode reads under auto-reset).  All generated
+        vertices are relaxed, front included.  Returns (sweeps int32 [n], diff float64 [n]); sweeps < 0: _capi.SMOOTH_*
+        (env untouched, e.g. SMOOTH_NOT_FINISHED for an episode that is still running / was truncated)."""
+        if which not in ("current", "last"):
+            raise ValueError("which must be 'current' or 'last'")
         t = self._torch
         if not hasattr(self, "smooth_sweeps"):
             self.smooth_sweeps = t.zeros(self.num_envs, dtype=t.int32, device=self.device)
@@ -317,7 +320,7 @@ class MeshVecEnv:
                 raise ValueError(f"mask must have shape ({self.num_envs},)")
             mptr = mask.data_ptr()
         self._bind_stream()
-        rc = self._L.meshenv_smooth_final(self._handle, mptr, int(iteration), float(lr_1), float(lr_2),
+        rc = self._L.meshenv_smooth_final(self._handle, 1 if which == "last" else 0, mptr, int(iteration), float(lr_1), float(lr_2),
                                           self.smooth_sweeps.data_ptr(), self.smooth_diff.data_ptr())
         self._check(rc, "meshenv_smooth_final")
         return self.smooth_sweeps, self.smooth_diff

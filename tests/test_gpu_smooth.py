@@ -309,3 +309,55 @@ def test_full_size_65536_envs_smooth_pave_with_front_smoother_sampled_oracle_sha
     steps(8)                               # the smoothed states are the states that are stepped on
     print("full-size smooth_pave: sweeps mean", float(sweeps.mean()), "max", int(sweeps.max()), "largest vertex deviation", worst)
     env.close()
+
+
+def test_smooth_of_the_archived_episode_equals_smooth_of_the_running_one(torch_cuda):
+    """meshenv_smooth_final(which = 1): under auto-reset the finished mesh lives in the archive half of the logs and its
+    front is gone with the ring; smooth() only needs the front's membership, which is recovered from the logs.  Two
+    batches on identical actions -- A without auto-reset (finished episodes wait, which = 0), B with it (which = 1 right
+    after the step that finished an episode) -- must produce the same sweeps and vertex tables, fronts of 4 and of 5."""
+    torch = torch_cuda
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv, _capi
+    tr13 = np.load(os.path.join(GOLDEN_DIR, "smoothfinal_ring13_s4.npz"))
+    trst = np.load(os.path.join(GOLDEN_DIR, "smoothfinal_star_s6.npz"))
+    doms = [[tuple(p) for p in tr13["domain_xy"]], [tuple(p) for p in trst["domain_xy"]]]
+    n, T = 1024, 90
+    env_domain = (np.arange(n) % 2).astype(np.int32)
+    a_env = MeshVecEnv(doms, env_domain=env_domain, log_capacity=128, auto_reset=False)
+    b_env = MeshVecEnv(doms, env_domain=env_domain, log_capacity=128, auto_reset=True)
+    a_env.reset(); b_env.reset()
+    rng = np.random.default_rng(31)
+    checked = fronts4 = fronts5 = 0
+    for t in range(T):
+        a = torch.from_numpy(_biased(rng, n)).cuda()
+        _, _, d_a, c_a = a_env.step(a)
+        _, _, d_b, c_b = b_env.step(a)
+        assert torch.equal(d_a, d_b) and torch.equal(c_a, c_b), t
+        fin = (d_a != 0) & (c_a != 0)
+        if fin.any():
+            sw_a, _ = a_env.smooth(mask=fin.to(torch.uint8), iteration=400, which="current")
+            sw_a = sw_a.cpu().numpy().copy()
+            sw_b, _ = b_env.smooth(mask=fin.to(torch.uint8), iteration=400, which="last")
+            sw_b = sw_b.cpu().numpy().copy()
+            idx = np.nonzero(fin.cpu().numpy())[0]
+            assert np.array_equal(sw_a[idx], sw_b[idx]) and (sw_a[idx] >= 1).all(), t
+            for k in idx[:24]:
+                qa, va = a_env.get_elements(int(k))
+                le = b_env.get_last_episode(int(k))
+                assert le["is_complete"] and np.array_equal(qa, le["quads"]) and np.array_equal(va, le["vertex_xy"]), (t, k)
+                front = a_env.get_state(int(k))["n"]
+                fronts4 += front == 4
+                fronts5 += front == 5
+                checked += 1
+        # A: everything that ended (complete or truncated) starts over, like B did by itself
+        if (d_a != 0).any():
+            a_env.reset(mask=(d_a != 0).to(torch.uint8))
+    # envs with nothing archived / a truncated last episode are refused
+    sw, _ = b_env.smooth(iteration=10, which="last")
+    sw = sw.cpu().numpy()
+    eps = np.array([b_env.get_last_episode(k)["episodes"] for k in range(0, n, 16)])
+    comp = np.array([b_env.get_last_episode(k)["is_complete"] for k in range(0, n, 16)])
+    assert ((sw[::16] == _capi.SMOOTH_NOT_FINISHED) == ((eps == 0) | ~comp)).all()
+    print("archive smoothing: meshes compared", checked, "fronts of 4 / 5:", int(fronts4), int(fronts5))
+    assert checked > 100 and fronts4 > 10 and fronts5 > 10
+    a_env.close(); b_env.close()
