@@ -215,7 +215,7 @@ int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, f
                  uint8_t *complete_dev, uint8_t *code_dev);
 
 /* MeshGeneration.smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=..., interior=...),
- * general/mesh.py:790-795, on the RUNNING episode of every env with mask_dev[e] != 0 (mask_dev NULL: all).  The
+ * general/mesh.py:790-795, on the RUNNING episode (which = 0) of every env with mask_dev[e] != 0 (mask_dev NULL: all).  The
  * Vertex.segments graph the reference walks is rebuilt from the element log, so the handle needs log_capacity > 0.
  *
  * interior != 0 (the post-processing call of general/EBRD.py:393): smooth_fixed_vertices (general/mesh.py:1258-1288) --
@@ -231,6 +231,11 @@ int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, f
  *   is_static != 0), the call move() makes right after smooth_pave -- and obs_dev [n_envs][18] (nullable) receives its
  *   observation (zeros where the reference returns None: status bit MESHENV_ST_NO_REFERENCE).
  *
+ * which = 1 (interior != 0 only): the same relaxation on the ARCHIVED episode of every selected env (the mesh
+ *   meshenv_get_last_episode reads, e.g. an episode that auto-reset ended by truncation); its front is recovered from the
+ *   logs (vertices on edges used an odd number of times by domain ring + elements); no candidate list is involved;
+ *   MESHENV_SMOOTH_NOT_FINISHED where nothing is archived yet.
+ *
  * The vertex log (meshenv_get_elements, meshenv_element_quality) holds the moved coordinates afterwards.
  *   sweeps_dev [n_envs] int32, nullable: sweeps of the interior relaxation; MESHENV_SMOOTH_SKIPPED for masked-out envs;
  *              MESHENV_SMOOTH_LOG_OVERFLOW (status bit MESHENV_ST_LOG_OVERFLOW: graph incomplete) and
@@ -244,8 +249,8 @@ enum {
     MESHENV_SMOOTH_INDEX_ERROR = -5,  /* the reference raises IndexError here (empty common-neighbour list) */
     MESHENV_SMOOTH_RAISES = -6
 };
-int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int interior, int is_static, int32_t *sweeps_dev,
-                   double *diff_dev, float *obs_dev);
+int meshenv_smooth(MeshEnv *h, int which, const uint8_t *mask_dev, int iteration, int interior, int is_static,
+                   int32_t *sweeps_dev, double *diff_dev, float *obs_dev);
 
 /* MeshGeneration.smooth(boundary.vertices, lr_1, lr_2, iteration), general/mesh.py:1290-1392 -- the post-processing of a
  * FINISHED mesh (general/EBRD.py:391: front of <= 5 vertices) -- on every env with mask_dev[e] != 0:

@@ -99,7 +99,7 @@ def load():
     L.meshenv_get_not_valid.argtypes = [vp, C.c_int, vp, C.c_int, i32p]
     L.meshenv_get_not_valid_ids.argtypes = [vp, C.c_int, vp, C.c_int, i32p, vp]
     L.meshenv_get_not_valid_ids.restype = C.c_int
-    L.meshenv_smooth.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.meshenv_smooth.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.meshenv_smooth.restype = C.c_int
     L.meshenv_smooth_final.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, C.c_double, vp, vp]
     L.meshenv_smooth_final.restype = C.c_int

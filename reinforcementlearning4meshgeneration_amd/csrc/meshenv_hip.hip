@@ -543,7 +543,7 @@ static int launch_full_smoothing(MeshEnv *h, const uint8_t *mask_dev, int iterat
     hipLaunchKernelGGL(k_smooth_front, grid, block, smooth_front_lds_bytes(h->cap, log_cap), h->stream, h->S, h->cap, mask_dev,
                        h->front_code);
     HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL(k_smooth_interior, grid, block, smooth_lds_bytes(h->cap, log_cap), h->stream, h->S, h->cap, mask_dev,
+    hipLaunchKernelGGL(k_smooth_interior, grid, block, smooth_lds_bytes(h->cap, log_cap), h->stream, h->S, h->cap, 0, mask_dev,
                        h->front_code, iteration, sw, diff_dev);
     HIP_TRY(h, hipGetLastError());
     if (is_static)
@@ -617,11 +617,13 @@ int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, f
     return MESHENV_OK;
 }
 
-int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int interior, int is_static, int32_t *sweeps_dev,
+int meshenv_smooth(MeshEnv *h, int which, const uint8_t *mask_dev, int iteration, int interior, int is_static, int32_t *sweeps_dev,
                    double *diff_dev, float *obs_dev)
 {
-    if (!h) return MESHENV_E_ARG;
+    if (!h || (which != 0 && which != 1)) return MESHENV_E_ARG;
     if (iteration < 0) return fail_arg(h, "meshenv_smooth: iteration must be >= 0");
+    if (which && !interior)
+        return fail_arg(h, "meshenv_smooth: the archived episode (which = 1) has no front to step on: interior must be != 0");
     const int log_cap = h->S.prm.log_cap;
     if (log_cap <= 0) {
         h->err = "meshenv_smooth: handle was created with log_capacity = 0 (the mesh graph is rebuilt from the element log)";
@@ -638,9 +640,10 @@ int meshenv_smooth(MeshEnv *h, const uint8_t *mask_dev, int iteration, int inter
     int32_t *sw = sweeps_dev ? sweeps_dev : h->smooth_sweeps;
     if (!interior) return launch_full_smoothing(h, mask_dev, iteration, is_static, sw, diff_dev, obs_dev);
     const dim3 grid(h->n_envs), block(64);
-    hipLaunchKernelGGL(k_smooth_interior, grid, block, lds, h->stream, h->S, h->cap, mask_dev, (const int32_t *)nullptr, iteration, sw,
-                       diff_dev);
+    hipLaunchKernelGGL(k_smooth_interior, grid, block, lds, h->stream, h->S, h->cap, which, mask_dev, (const int32_t *)nullptr,
+                       iteration, sw, diff_dev);
     HIP_TRY(h, hipGetLastError());
+    if (which) return MESHENV_OK;   // an archived mesh: nothing to step on, no candidate list
     hipLaunchKernelGGL(k_rebuild_candidates<0>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
                        (float *)nullptr);
     HIP_TRY(h, hipGetLastError());

@@ -110,8 +110,8 @@ __device__ __forceinline__ bool build_segment_lists(const int4 *__restrict__ qua
 // reference's loop), or kSmoothSkipped (masked out), kSmoothLogOverflow (graph incomplete: nothing changed),
 // kSmoothDegree.  diff_out[env]: the last |sum - previous sum| (the number the reference prints).
 __global__ void __launch_bounds__(64)
-k_smooth_interior(DevState S, int ring_cap, const uint8_t *__restrict__ mask, const int32_t *__restrict__ gate, int iteration,
-                  int32_t *__restrict__ sweeps_out, double *__restrict__ diff_out)
+k_smooth_interior(DevState S, int ring_cap, int which, const uint8_t *__restrict__ mask, const int32_t *__restrict__ gate,
+                  int iteration, int32_t *__restrict__ sweeps_out, double *__restrict__ diff_out)
 {
     extern __shared__ double2 smem[];
     const int env = blockIdx.x, lane = lane_id();
@@ -126,15 +126,28 @@ k_smooth_interior(DevState S, int ring_cap, const uint8_t *__restrict__ mask, co
     const int log_cap = S.prm.log_cap;
     const EnvScalars sc = S.scal[env];
     const DevCold cold = load_cold(S);
-    const int n = uniform_i32(sc.n), n_elem = uniform_i32(sc.n_elem), n_new = uniform_i32(sc.n_new);
+    int n = uniform_i32(sc.n), n_elem = uniform_i32(sc.n_elem), n_new = uniform_i32(sc.n_new);
     const int status = uniform_i32(sc.status);
-    if ((status & kStLogOverflow) || n_elem > log_cap || n_new > log_cap) {
+    bool overflow = (status & kStLogOverflow) != 0;
+    int half = (status >> 4) & 1;
+    if (which) {   // the archived episode (meshenv_get_last_episode): its front is read off the logs, see build_segment_lists
+        const LastEpisode le = cold.last_ep[env];
+        if (uniform_i32(le.episodes) <= 0) {
+            if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothNotFinished;
+            return;
+        }
+        n_elem = uniform_i32(le.n_elem); n_new = uniform_i32(le.n_new);
+        overflow = (uniform_i32(le.flags) & 2) != 0;
+        half ^= 1;
+        n = 0;
+    }
+    if (overflow || n_elem > log_cap || n_new > log_cap) {
         if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothLogOverflow;
         return;
     }
     const DomConst dc = S.dom[uniform_i32(sc.dom)];
     const int doff = uniform_i32(dc.off), n0 = uniform_i32(dc.n0);
-    const size_t lbase = ((size_t)env * 2 + ((status >> 4) & 1)) * log_cap;
+    const size_t lbase = ((size_t)env * 2 + half) * log_cap;
     const int4 *quads = reinterpret_cast<const int4 *>(cold.log_quads + lbase * 4);
     double2 *vnew = cold.log_vxy + lbase;
 
@@ -158,7 +171,7 @@ k_smooth_interior(DevState S, int ring_cap, const uint8_t *__restrict__ mask, co
         if (g & kNewBit) front[g & ~kNewBit] = 1;
     }
     // the neighbour lists: one lane per generated vertex, the element log read by all lanes at the same address
-    const bool too_many = build_segment_lists(quads, n_elem, n0, n0, n_new, adj, deg, nullptr);
+    const bool too_many = build_segment_lists(quads, n_elem, n0, n0, n_new, adj, deg, nullptr, which ? front : nullptr);
     if (__ballot(too_many) != 0ULL) {
         if (lane == 0 && sweeps_out) sweeps_out[env] = kSmoothDegree;
         return;

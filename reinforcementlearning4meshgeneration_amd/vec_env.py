@@ -271,7 +271,8 @@ class MeshVecEnv:
         self._check(rc, "meshenv_move")
         return self.obs, self.done, self.complete, self.move_code
 
-    def smooth_pave(self, mask=None, iteration: int = 400, interior: bool = True, static: bool = False):
+    def smooth_pave(self, mask=None, iteration: int = 400, interior: bool = True, static: bool = False,
+                    which: str = "current"):
         """MeshGeneration.smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=iteration, interior=interior)
         (general/mesh.py:790-795) on the running episode of every env (mask: uint8/bool CUDA [n], None = all).  Needs
         log_capacity > 0; the vertex log (`generated_meshes`, the quality report) holds the moved coordinates afterwards.
@@ -282,8 +283,13 @@ class MeshVecEnv:
         generated vertices first; then, the front having moved, the point environment is recomputed at once
         (find_next_state(static=static)) and `self.obs` holds its observation.
 
+        which="last" (interior=True only): the same relaxation on the archived episode of every env (what
+        get_last_episode reads under auto-reset, e.g. an episode ended by truncation).
+
         Returns (sweeps int32 [n], diff float64 [n]); sweeps < 0: _capi.SMOOTH_* (SMOOTH_RAISES: the reference raises
         inside the front smoother; the env keeps what had moved until then)."""
+        if which not in ("current", "last"):
+            raise ValueError("which must be 'current' or 'last'")
         t = self._torch
         if not hasattr(self, "smooth_sweeps"):
             self.smooth_sweeps = t.zeros(self.num_envs, dtype=t.int32, device=self.device)
@@ -295,7 +301,8 @@ class MeshVecEnv:
                 raise ValueError(f"mask must have shape ({self.num_envs},)")
             mptr = mask.data_ptr()
         self._bind_stream()
-        rc = self._L.meshenv_smooth(self._handle, mptr, int(iteration), 1 if interior else 0, 1 if static else 0,
+        rc = self._L.meshenv_smooth(self._handle, 1 if which == "last" else 0, mptr, int(iteration), 1 if interior else 0,
+                                    1 if static else 0,
                                     self.smooth_sweeps.data_ptr(), self.smooth_diff.data_ptr(),
                                     None if interior else self.obs.data_ptr())
         self._check(rc, "meshenv_smooth")

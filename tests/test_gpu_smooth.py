@@ -361,3 +361,48 @@ def test_smooth_of_the_archived_episode_equals_smooth_of_the_running_one(torch_c
     print("archive smoothing: meshes compared", checked, "fronts of 4 / 5:", int(fronts4), int(fronts5))
     assert checked > 100 and fronts4 > 10 and fronts5 > 10
     a_env.close(); b_env.close()
+
+
+def test_smooth_pave_of_the_archived_episode_equals_the_running_one(torch_cuda):
+    """meshenv_smooth(which = 1): smooth_pave(interior=True) on the archive half (e.g. an episode auto-reset ended by
+    truncation or completion).  Batch A never resets by itself and is smoothed in place at step T; batch B is reset
+    explicitly for ALL envs right after step T (which archives every episode that has elements) and its archive is
+    smoothed: same sweeps, same vertex tables, for every env with at least one element."""
+    torch = torch_cuda
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv, _capi, boundary
+    n, T = 2048, 70
+    a_env = MeshVecEnv([boundary(0)], n_envs=n, log_capacity=128, auto_reset=False)
+    b_env = MeshVecEnv([boundary(0)], n_envs=n, log_capacity=128, auto_reset=False)
+    a_env.reset(); b_env.reset()
+    rng = np.random.default_rng(41)
+    alive = torch.ones(n, dtype=torch.bool, device="cuda")
+    for t in range(T):
+        a = torch.from_numpy(_biased(rng, n)).cuda()
+        _, _, d_a, _ = a_env.step(a)
+        _, _, d_b, _ = b_env.step(a)
+        assert torch.equal(d_a, d_b)
+        alive &= d_a == 0
+        if (d_a != 0).any():     # keep both batches on running episodes (restart what ended, in both)
+            m = (d_a != 0).to(torch.uint8)
+            a_env.reset(mask=m); b_env.reset(mask=m)
+    sw_a, _ = a_env.smooth_pave(iteration=400, interior=True, which="current")
+    sw_a = sw_a.cpu().numpy().copy()
+    n_elem = np.array([a_env.get_state(k)["n_elem"] for k in range(n)])
+    b_env.reset()                # archives the running episode of every env that has elements
+    sw_b, _ = b_env.smooth_pave(iteration=400, interior=True, which="last")
+    sw_b = sw_b.cpu().numpy().copy()
+    have = n_elem > 0
+    eps = np.array([b_env.get_last_episode(k)["episodes"] for k in range(n)])
+    assert np.array_equal(sw_a[have & (eps > 0)], sw_b[have & (eps > 0)])
+    assert (sw_b[eps == 0] == _capi.SMOOTH_NOT_FINISHED).all()
+    cmp = 0
+    for k in np.nonzero(have & (eps > 0))[0][::9]:
+        qa, va = a_env.get_elements(int(k))
+        le = b_env.get_last_episode(int(k))
+        assert np.array_equal(qa, le["quads"]) and np.array_equal(va, le["vertex_xy"]), k
+        cmp += 1
+    print("archived smooth_pave: envs compared", cmp, "mean sweeps", float(sw_b[have & (eps > 0)].mean()))
+    assert cmp > 100
+    with pytest.raises(_capi.MeshEnvError):
+        b_env.smooth_pave(interior=False, which="last")
+    a_env.close(); b_env.close()
