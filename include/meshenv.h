@@ -202,8 +202,9 @@ enum {
     MESHENV_MOVE_NEEDS_SMOOTHING = 3, /* only on handles without a usable element log (log_capacity = 0, overflow, or
                                          too large for the smoother's LDS): the smooth_pave below cannot be run and the
                                          episode ends instead, done = 1, complete = 0 */
-    MESHENV_MOVE_SMOOTH_RAISES = 4    /* the reference raises inside that smooth_pave (math domain error / division by
-                                         zero in a vertex construction): done = 1, the caller resets */
+    MESHENV_MOVE_SMOOTH_RAISES = 4    /* a vertex construction inside that smooth_pave is undefined (MESHENV_SMOOTH_RAISES
+                                         below: the reference raises, or goes on with NaN coordinates): done = 1, the
+                                         caller resets */
 };
 /* No selectable reference vertex on a front of more than 4 vertices (every candidate is listed in not_valid_points):
  * the reference runs smooth_pave (front + interior smoothing, candidate rebuild; rl/boundary_env.py:405-412), ends the
@@ -240,8 +241,11 @@ int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, f
  *   sweeps_dev [n_envs] int32, nullable: sweeps of the interior relaxation; MESHENV_SMOOTH_SKIPPED for masked-out envs;
  *              MESHENV_SMOOTH_LOG_OVERFLOW (status bit MESHENV_ST_LOG_OVERFLOW: graph incomplete) and
  *              MESHENV_SMOOTH_DEGREE (a vertex with more than 16 neighbours) leave the env untouched;
- *              MESHENV_SMOOTH_RAISES: the reference raises inside the front smoother (math domain error / division by
- *              zero in a vertex construction) -- the vertices moved before that point stay moved, nothing else ran
+ *              MESHENV_SMOOTH_RAISES: a vertex construction of the front smoother is undefined (math.sqrt of a negative
+ *              number, division by zero: coincident front vertices) -- the vertices moved before that point stay
+ *              moved, nothing else ran.  The reference raises there when the operands are Python floats; when a NumPy
+ *              scalar is involved (coordinates of generated vertices are) a zero divisor only warns and it goes on
+ *              with inf / NaN coordinates -- that continuation is not reproduced
  *   diff_dev   [n_envs] float64, nullable: the last |sum - previous sum| (what the reference prints) */
 enum {
     MESHENV_SMOOTH_SKIPPED = -1, MESHENV_SMOOTH_LOG_OVERFLOW = -2, MESHENV_SMOOTH_DEGREE = -3,

@@ -1187,9 +1187,10 @@ int meshenv_ref_smooth_final(RefEnv *e, int iteration, double lr_1, double lr_2,
  * interior angle: <= 90 -> middle_vertex on the bisector for a target angle raised in steps of 5 until the new position
  * keeps every surrounding element on its side (is_inside_boundary over clockwise_vertices); (90, 180] -> side_vertex
  * next to a sharp (< 45) neighbour corner, else find_indention_vertex; (180, 270] -> find_indention_vertex; beyond ->
- * inner_vertex then find_indention_vertex.  Returns 0, -1 (log / degree overflow), -3 where the reference raises
- * (ValueError from math.sqrt of a negative number, ZeroDivisionError): the vertices moved before that stay moved, as in
- * the reference. */
+ * inner_vertex then find_indention_vertex.  Returns 0, -1 (log / degree overflow), -3 where a vertex construction is
+ * undefined (math.sqrt of a negative number: ValueError in the reference; a zero divisor: ZeroDivisionError in the
+ * reference if both operands are Python floats -- with a NumPy scalar involved it only warns and continues with inf / NaN
+ * coordinates, which is NOT restated): the vertices moved before that stay moved. */
 typedef struct {
     RefEnv *e;
     Graph g;
