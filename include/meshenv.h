@@ -277,7 +277,7 @@ int meshenv_get_not_valid(MeshEnv *h, int env, double *xy_host, int cap_points, 
 /* The same list as vertex ids (the reference's list holds Vertex objects: identity), and the summary of
  * last_not_valid_points (rl/boundary_env.py:48,416-422: set where move() smooths, compared by first entry, last entry and
  * length, never cleared by reset()): last_host[4] = first id, last id, length, 1 if it was recorded in the running
- * episode (a generated vertex of an earlier episode is a different object).  ids_host / last_host nullable. */
+ * episode (reset() deep-copies the domain, rl/boundary_env.py:69: vertices of an earlier episode are different objects).  ids_host / last_host nullable. */
 int meshenv_get_not_valid_ids(MeshEnv *h, int env, int32_t *ids_host, int cap_ids, int32_t *count, int32_t *last_host);
 
 /*

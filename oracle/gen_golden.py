@@ -194,6 +194,12 @@ MOVE_TRACES = [
     ("move_hexagon_s3", HEXAGON, 3, 120, False),     # completes in one or two moves; then the reference raises
     ("move_octagon_s4", OCTAGON, 4, 200, False),
     ("move_heptagon_s5", HEPTAGON, 5, 120, False),
+    # more of move()'s smooth_pave branch (B:405-426), incl. the front smoother's side_vertex constructions (sharp corners)
+    ("move_dolphine3_s11", "dolphine3", 11, 500, True),
+    ("move_star_s13", "star", 13, 500, True),
+    ("move_rand903_s903", "RANDOM903", 903, 500, True),
+    ("move_rand928_s928", "RANDOM928", 928, 500, True),
+    ("move_rand906_s906", "RANDOM906", 906, 500, True),
 ]
 
 
@@ -263,12 +269,17 @@ def main_front_smooth():
 
 def main_move():
     for name, dom, seed, T, reset_on_done in MOVE_TRACES:
-        pts = H.domain_points(dom) if isinstance(dom, str) else dom
+        if isinstance(dom, str) and dom.startswith("RANDOM"):
+            from reinforcementlearning4meshgeneration_amd.domains import random_domain
+            pts = random_domain(int(dom[6:]))
+        else:
+            pts = H.domain_points(dom) if isinstance(dom, str) else dom
         p, ty = H.move_inputs(seed, T)
         tr = H.record_move_trace(pts, p, ty, reset_on_done=reset_on_done)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **tr)
         print(f"{name}: {T} moves, {int(tr['valid'].sum())} valid, codes {np.bincount(tr['code'], minlength=4).tolist()}, "
-              f"done {int(tr['done'].sum())}, complete {int(tr['complete'].sum())}, max not_valid {int(tr['n_not_valid'].max())}")
+              f"done {int(tr['done'].sum())}, complete {int(tr['complete'].sum())}, max not_valid {int(tr['n_not_valid'].max())}, "
+              f"through smooth_pave {int(tr['smoothed'].sum())}")
 
 
 def main():

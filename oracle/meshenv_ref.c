@@ -72,7 +72,7 @@ struct RefEnv {
     int32_t *nv_id;    /* global vertex id of each listed vertex (the list holds Vertex objects: identity) */
     int n_nv;
     /* last_not_valid_points (B:48, 416-422): set only where move() smooths, NOT cleared by reset() -- first / last entry
-     * and length are all the reference compares; a generated vertex is the same object only within one episode */
+     * and length are all the reference compares; a vertex is the same object only within one episode (reset() deep-copies) */
     int32_t last_first, last_last, last_count, last_epoch, epoch;
     /* logs */
     int cap_v, cap_e;
@@ -905,9 +905,9 @@ int meshenv_ref_move(RefEnv *e, const double *point, double type, float *obs, ui
             }
             if (e->last_count > 0 && e->n_nv > 0) {
                 const int32_t f = e->nv_id[0], l = e->nv_id[e->n_nv - 1];
-                const int same_f = f == e->last_first && (f < e->n0 || e->last_epoch == e->epoch);
-                const int same_l = l == e->last_last && (l < e->n0 || e->last_epoch == e->epoch);
-                if (same_f && same_l && e->n_nv == e->last_count) done = 1;
+                /* reset() deep-copies the domain (B:69): every vertex of an earlier episode is a different object */
+                const int same_episode = e->last_epoch == e->epoch;
+                if (same_episode && f == e->last_first && l == e->last_last && e->n_nv == e->last_count) done = 1;
             }
             e->last_count = e->n_nv;
             if (e->n_nv > 0) { e->last_first = e->nv_id[0]; e->last_last = e->nv_id[e->n_nv - 1]; }

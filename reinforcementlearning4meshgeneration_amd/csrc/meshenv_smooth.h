@@ -999,9 +999,8 @@ __global__ void k_move_finish(DevState S, int cap, const uint8_t *__restrict__ m
     const int first = cnt > 0 ? nv_gid[(size_t)e * cap] : 0, last = cnt > 0 ? nv_gid[(size_t)e * cap + cnt - 1] : 0;
     bool dn = false;
     if (m[3] > 0 && cnt > 0) {
-        const bool same_f = first == m[1] && ((first & kNewBit) == 0 || m[4] == epoch);
-        const bool same_l = last == m[2] && ((last & kNewBit) == 0 || m[4] == epoch);
-        dn = same_f && same_l && cnt == m[3];
+        // reset() deep-copies the domain (B:69): every vertex of an earlier episode is a different object
+        dn = m[4] == epoch && first == m[1] && last == m[2] && cnt == m[3];
     }
     m[1] = first; m[2] = last; m[3] = cnt; m[4] = epoch;   // self.last_not_valid_points = self.not_valid_points
     nv_count[e] = 0;                                        // self.not_valid_points = []
