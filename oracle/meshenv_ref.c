@@ -1406,6 +1406,22 @@ static int build_full_graph(const RefEnv *e, Graph *g)
     return rc;
 }
 
+/* the three vertex constructions as plain functions (unit tests against the reference's methods, tests/test_oracle_smooth.py):
+ * which = 0 middle_vertex(vertex, left, right, target_angle), 1 side_vertex(vertex, next, nn, angle, dist),
+ * 2 indention_vertex(vertex, left, right, angle, dist).  in[8] = vertex, p1, p2 (x, y each), angle, dist; returns 1 where
+ * the construction is undefined (the reference raises). */
+int meshenv_ref_front_construction(int which, const double *in, double *out_xy)
+{
+    Front f;
+    f.e = NULL; f.g.adj = NULL; f.g.deg = NULL; f.raised = 0;
+    P2 v = {in[0], in[1]}, a = {in[2], in[3]}, b = {in[4], in[5]}, r;
+    if (which == 0) r = middle_vertex(&f, v, a, b, in[6]);
+    else if (which == 1) r = side_vertex(&f, v, a, b, in[6], in[7]);
+    else r = indention_vertex(&f, v, a, b, in[6], in[7]);
+    out_xy[0] = r.x; out_xy[1] = r.y;
+    return f.raised;
+}
+
 int meshenv_ref_smooth_front(RefEnv *e)
 {
     if (e->n_elem > e->cap_e || e->n_vert > e->cap_v) return -1;

@@ -68,6 +68,8 @@ int meshenv_ref_smooth_interior(RefEnv *e, int iteration, int32_t *sweeps_out, d
  * branch_out[3]: vertex visits with 1 / 2 / other numbers of related elements; -2 = the reference raises IndexError */
 int meshenv_ref_smooth_final(RefEnv *e, int iteration, double lr_1, double lr_2, int32_t *sweeps_out, double *diff_out,
                              int64_t *branch_out);
+/* middle_vertex / side_vertex / indention_vertex (general/mesh.py:805-909) as plain functions, for unit tests */
+int meshenv_ref_front_construction(int which, const double *in /*[8]*/, double *out_xy /*[2]*/);
 /* smooth_current_boundary_3 (general/mesh.py:939-1028) alone; -3 = the reference raises (ValueError / ZeroDivisionError) */
 int meshenv_ref_smooth_front(RefEnv *e);
 /* smooth_pave(..., interior=False) + the find_next_state that follows it in move() (rl/boundary_env.py:405-420) */

@@ -47,6 +47,8 @@ def lib():
     L.meshenv_ref_smooth_final.restype = C.c_int
     L.meshenv_ref_smooth_final.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, _i32p, _f64p,
                                            np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
+    L.meshenv_ref_front_construction.restype = C.c_int
+    L.meshenv_ref_front_construction.argtypes = [C.c_int, _f64p, _f64p]
     L.meshenv_ref_smooth_front.restype = C.c_int
     L.meshenv_ref_smooth_front.argtypes = [C.c_void_p]
     L.meshenv_ref_smooth_pave_full.restype = C.c_int

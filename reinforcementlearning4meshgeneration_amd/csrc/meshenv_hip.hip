@@ -1023,6 +1023,19 @@ __global__ void k_selftest(int what, int n, const double *in, double *out)
         const double f = cw_fast(in[2 * i], in[2 * i + 1], ne);
         const double e = cw_finish(atan2(in[2 * i], in[2 * i + 1]));
         out[i] = ne ? 1.0 : ((f == e && signbit(f) == signbit(e)) ? 0.0 : 2.0);
+    } else if (what == 9 || what == 10) {
+        // the front smoother's vertex constructions (csrc/meshenv_smooth.h): 9 doubles = which (0 middle_vertex, 1 side_vertex,
+        // 2 indention_vertex), vertex, p1, p2, angle, dist; what 9 -> x, 10 -> y; NaN where the construction is undefined
+        const double *q = in + 9 * (size_t)i;
+        FrontState f;
+        f.coord = nullptr; f.adj = nullptr; f.deg = nullptr; f.ringu = nullptr; f.n = 0; f.raised = false;
+        const P2 v = mkp(q[1], q[2]), a = mkp(q[3], q[4]), b = mkp(q[5], q[6]);
+        const int which = (int)q[0];
+        P2 r;
+        if (which == 0) r = middle_vertex(v, a, b, q[7]);
+        else if (which == 1) r = side_vertex(f, v, a, b, q[7], q[8]);
+        else r = indention_vertex(f, v, a, b, q[7], q[8]);
+        out[i] = f.raised ? __builtin_nan("") : (what == 9 ? r.x : r.y);
     }
 }
 

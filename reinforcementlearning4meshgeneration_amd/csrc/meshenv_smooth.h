@@ -619,6 +619,25 @@ __device__ __forceinline__ P2 middle_vertex(P2 vertex, P2 left, P2 right, double
     return dist(v1, vertex) < dist(v2, vertex) ? v1 : v2;
 }
 
+// M:834-863
+__device__ __forceinline__ P2 side_vertex(FrontState &f, P2 vertex, P2 next_v, P2 nn_v, double angle, double d)
+{
+    const double W = d * dist(next_v, nn_v) * cos(deg2rad(angle));
+    P2 v1, v2;
+    circle_line(f, next_v.x, next_v.y, nn_v.x - next_v.x, nn_v.y - next_v.y, W, d, v1, v2);
+    return dist(v1, vertex) < dist(v2, vertex) ? v1 : v2;
+}
+
+// M:882-909
+__device__ __forceinline__ P2 indention_vertex(FrontState &f, P2 vertex, P2 left, P2 right, double angle, double d)
+{
+    const double W = d * dist(vertex, left) * cos(deg2rad(angle));
+    P2 v1, v2;
+    circle_line(f, vertex.x, vertex.y, left.x - vertex.x, left.y - vertex.y, W, d, v1, v2);
+    if (f.raised) return vertex;
+    return cw(v1, left, right) < cw(v2, left, right) ? v1 : v2;
+}
+
 // clockwise_vertices, M:1080-1101: the neighbours of `inner` sorted by clockwise angle (the selection sort as written),
 // each followed by the common neighbour it shares with its successor.  out (LDS, 2 x kSmoothMaxDeg): vertex indices.
 __device__ __forceinline__ int clockwise_vertices(const FrontState &f, int inner, unsigned short *out)
@@ -704,11 +723,8 @@ __device__ __forceinline__ P2 find_side_vertex(FrontState &f, int v, int _next, 
     const double d = (dist(pv, ldc(f, _next)) + dist(pv, pn) + dist(pn, pnn)) / 3;
     double target = 45;
     for (int guard = 0; guard < 16; guard++) {
-        const double W = d * dist(pn, pnn) * cos(deg2rad(target));
-        P2 v1, v2;
-        circle_line(f, pn.x, pn.y, pnn.x - pn.x, pnn.y - pn.y, W, d, v1, v2);
+        const P2 nv = side_vertex(f, pv, pn, pnn, target, d);
         if (f.raised) return pv;
-        const P2 nv = dist(v1, pv) < dist(v2, pv) ? v1 : v2;
         if (target <= v_angle) return pv;
         const int nb = clockwise_vertices(f, v, cb);
         if (is_inside_boundary(f, pv, nv, cb, nb, _next, next)) return nv;
@@ -749,12 +765,8 @@ __device__ __forceinline__ P2 find_indention_vertex(FrontState &f, int index, do
     if (__ballot(zero_div) != 0ULL) { f.raised = true; return pv; }
     if (__ballot(near) == 0ULL) return pv;
     for (int times = 4; ; times++) {
-        const double dd = d / times;
-        const double W = dd * dist(pv, pl) * cos(deg2rad((360 - v_angle) / 2));
-        P2 v1, v2;
-        circle_line(f, pv.x, pv.y, pl.x - pv.x, pl.y - pv.y, W, dd, v1, v2);
+        const P2 nv = indention_vertex(f, pv, pl, pr, (360 - v_angle) / 2, d / times);
         if (f.raised) return pv;
-        const P2 nv = cw(v1, pl, pr) < cw(v2, pl, pr) ? v1 : v2;
         if (times >= 10) return pv;
         const int nb = clockwise_vertices(f, v, cb);
         if (is_inside_boundary(f, pv, nv, cb, nb, left, right)) return nv;

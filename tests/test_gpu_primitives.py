@@ -147,3 +147,22 @@ def test_fast_quantised_angle_equals_the_exact_form():
     near = np.abs(off) <= 1e-10
     assert (bnd[near] == 1.0).all()                          # ... and it does fire at the boundaries
     assert (out[-len(special):][[4, 5, 6, 7]] == 1.0).all()  # atan2(0, 0) family -> exact form
+
+
+def test_front_smoother_vertex_constructions_match_the_reference_known_answers():
+    """middle_vertex / side_vertex / indention_vertex (general/mesh.py:805-909) on the device against 12 000 evaluations
+    recorded from the reference (tests/golden/front_constructions.npz: random, axis-aligned and grid inputs): undefined
+    exactly where the reference raises, otherwise within 1e-11 relative (tan / cos of ocml vs libm feed a quadratic)."""
+    import os
+    from conftest import GOLDEN_DIR
+    tr = np.load(os.path.join(GOLDEN_DIR, "front_constructions.npz"))
+    items = np.ascontiguousarray(tr["inputs"])
+    x = _run(9, items)
+    y = _run(10, items)
+    bad = tr["raised"].astype(bool)
+    assert np.array_equal(np.isnan(x), bad) and np.array_equal(np.isnan(y), bad)
+    got = np.stack([x, y], axis=1)[~bad]
+    want = tr["outputs"][~bad]
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    print("constructions: max relative deviation", err.max(), "exact", float((got == want).mean()))
+    assert err.max() <= 1e-11

@@ -89,3 +89,21 @@ def test_oracle_front_smoother_matches_reference_records(name):
     tr = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
     worst, front_moves = replay_front(tr, OracleImpl(tr))
     assert int(tr["n_calls"]) >= 5 and front_moves > 0
+
+
+def test_front_constructions_match_the_reference_known_answers():
+    """middle_vertex / side_vertex / indention_vertex (general/mesh.py:805-909): 12 000 evaluations by the reference itself
+    (random, axis-aligned -- the B == 0 / A == 0 branches -- and grid inputs; oracle/gen_construction_golden.py), the
+    oracle's bit for bit, including the inputs on which the reference raises."""
+    from oracle.ref_lib import lib
+    L = lib()
+    tr = np.load(os.path.join(GOLDEN_DIR, "front_constructions.npz"))
+    out = np.zeros(2, np.float64)
+    seen_raise = 0
+    for row, want, bad in zip(tr["inputs"], tr["outputs"], tr["raised"]):
+        rc = L.meshenv_ref_front_construction(int(row[0]), np.ascontiguousarray(row[1:9]), out)
+        assert rc == int(bad), (row, rc, bad)
+        if not bad:
+            assert np.array_equal(out, want), (row, out, want)
+        seen_raise += int(bad)
+    assert seen_raise > 10
