@@ -396,7 +396,8 @@ int meshenv_actor_sample(MeshActor *a, int n, const float *obs_dev, uint64_t see
  *        5 round(np.float32, 4)      6 Point2D.distance_to (4 doubles)   7 sqrt_pos == sqrt (1 double)
  *        8 quantised clockwise angle, fast form against exact (2 doubles: c, d): 0 equal, 1 guard band, 2 mismatch
  *        9 / 10 x / y of a front-smoother vertex construction (9 doubles: which = 0 middle_vertex, 1 side_vertex,
- *               2 indention_vertex (general/mesh.py:805-909); vertex, p1, p2; angle; dist), NaN where it is undefined
+ *               2 indention_vertex (general/mesh.py:805-909), 3 Mesh.estimate_4th_vertex (factor, suggest_dist or < 0);
+ *               vertex, p1, p2; angle; dist), NaN where it is undefined
  */
 int meshenv_selftest(int device, int what, int n, int in_per_item, const double *in_host, double *out_host);
 

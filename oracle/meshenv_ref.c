@@ -1408,7 +1408,8 @@ static int build_full_graph(const RefEnv *e, Graph *g)
 
 /* the three vertex constructions as plain functions (unit tests against the reference's methods, tests/test_oracle_smooth.py):
  * which = 0 middle_vertex(vertex, left, right, target_angle), 1 side_vertex(vertex, next, nn, angle, dist),
- * 2 indention_vertex(vertex, left, right, angle, dist).  in[8] = vertex, p1, p2 (x, y each), angle, dist; returns 1 where
+ * 2 indention_vertex(vertex, left, right, angle, dist), 3 Mesh.estimate_4th_vertex(origin, left, right, factor,
+ * suggest_dist; dist < 0: None; general/components.py:980-990).  in[8] = vertex, p1, p2 (x, y each), angle, dist; returns 1 where
  * the construction is undefined (the reference raises). */
 int meshenv_ref_front_construction(int which, const double *in, double *out_xy)
 {
@@ -1417,7 +1418,8 @@ int meshenv_ref_front_construction(int which, const double *in, double *out_xy)
     P2 v = {in[0], in[1]}, a = {in[2], in[3]}, b = {in[4], in[5]}, r;
     if (which == 0) r = middle_vertex(&f, v, a, b, in[6]);
     else if (which == 1) r = side_vertex(&f, v, a, b, in[6], in[7]);
-    else r = indention_vertex(&f, v, a, b, in[6], in[7]);
+    else if (which == 2) r = indention_vertex(&f, v, a, b, in[6], in[7]);
+    else r = estimate_4th_vertex(v, a, b, in[6], in[7] >= 0, in[7]); /* 3: Mesh.estimate_4th_vertex(origin, left, right, factor, suggest_dist | None) */
     out_xy[0] = r.x; out_xy[1] = r.y;
     return f.raised;
 }

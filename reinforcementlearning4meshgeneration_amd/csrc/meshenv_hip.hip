@@ -1034,7 +1034,11 @@ __global__ void k_selftest(int what, int n, const double *in, double *out)
         P2 r;
         if (which == 0) r = middle_vertex(v, a, b, q[7]);
         else if (which == 1) r = side_vertex(f, v, a, b, q[7], q[8]);
-        else r = indention_vertex(f, v, a, b, q[7], q[8]);
+        else if (which == 2) r = indention_vertex(f, v, a, b, q[7], q[8]);
+        else {  // 3: Mesh.estimate_4th_vertex(origin, left, right, factor, suggest_dist or < 0 for None)
+            const double2 e = estimate_4th_vertex(make_double2(v.x, v.y), make_double2(a.x, a.y), make_double2(b.x, b.y), q[7], q[8] >= 0, q[8]);
+            r = mkp(e.x, e.y);
+        }
         out[i] = f.raised ? __builtin_nan("") : (what == 9 ? r.x : r.y);
     }
 }

@@ -150,7 +150,7 @@ def test_fast_quantised_angle_equals_the_exact_form():
 
 
 def test_front_smoother_vertex_constructions_match_the_reference_known_answers():
-    """middle_vertex / side_vertex / indention_vertex (general/mesh.py:805-909) on the device against 12 000 evaluations
+    """middle_vertex / side_vertex / indention_vertex (general/mesh.py:805-909) on the device against 16 000 evaluations
     recorded from the reference (tests/golden/front_constructions.npz: random, axis-aligned and grid inputs): undefined
     exactly where the reference raises, otherwise within 1e-11 relative (tan / cos of ocml vs libm feed a quadratic)."""
     import os

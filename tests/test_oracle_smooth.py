@@ -92,7 +92,8 @@ def test_oracle_front_smoother_matches_reference_records(name):
 
 
 def test_front_constructions_match_the_reference_known_answers():
-    """middle_vertex / side_vertex / indention_vertex (general/mesh.py:805-909): 12 000 evaluations by the reference itself
+    """middle_vertex / side_vertex / indention_vertex (general/mesh.py:805-909) and Mesh.estimate_4th_vertex: 16 000
+    evaluations by the reference itself
     (random, axis-aligned -- the B == 0 / A == 0 branches -- and grid inputs; oracle/gen_construction_golden.py), the
     oracle's bit for bit, including the inputs on which the reference raises."""
     from oracle.ref_lib import lib
