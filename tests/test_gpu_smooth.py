@@ -406,3 +406,34 @@ def test_smooth_pave_of_the_archived_episode_equals_the_running_one(torch_cuda):
     with pytest.raises(_capi.MeshEnvError):
         b_env.smooth_pave(interior=False, which="last")
     a_env.close(); b_env.close()
+
+
+def test_fused_rollout_continues_from_a_front_smoothed_state(torch_cuda):
+    """After smooth_pave(interior=False) the point environment is committed at once (no parked re-selection), so a fused
+    multi-step rollout (k_step<true>, state held in LDS across steps) may follow directly: 512 envs, 16 steps in one
+    launch, flags and rewards against the oracle stepping from its own smoothed state."""
+    torch = torch_cuda
+    from oracle.ref_lib import RefBatch, RefEnv
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv, boundary
+    n, T0, T1 = 512, 30, 16
+    env = MeshVecEnv([boundary(0)], n_envs=n, log_capacity=96, auto_reset=True)
+    refs = [RefEnv.from_points(boundary(0), cap_new=96) for _ in range(n)]
+    batch = RefBatch(refs)
+    assert np.array_equal(env.reset().cpu().numpy(), batch.reset())
+    rng = np.random.default_rng(63)
+    for t in range(T0):
+        a = _biased(rng, n)
+        env.step(torch.from_numpy(a).cuda())
+        batch.step(a, auto_reset=True, threads=16)
+    sweeps, _ = env.smooth_pave(iteration=400, interior=False)
+    assert (sweeps.cpu().numpy() >= 1).all()
+    for r in refs:
+        assert r.smooth_pave_full(400)[0] == 0
+    acts = np.stack([_biased(rng, n) for _ in range(T1)])
+    obs, rew, done, comp = env.rollout(torch.from_numpy(acts).cuda())
+    for t in range(T1):
+        o_ref, r_ref, d_ref, c_ref = batch.step(acts[t], auto_reset=True, threads=16)
+        assert np.array_equal(done[t].cpu().numpy(), d_ref) and np.array_equal(comp[t].cpu().numpy(), c_ref), t
+        assert np.abs(rew[t].cpu().numpy() - r_ref).max() <= 1e-5, t
+    assert np.abs(obs.cpu().numpy().astype(np.float64) - o_ref).max() <= 1e-5
+    env.close()
