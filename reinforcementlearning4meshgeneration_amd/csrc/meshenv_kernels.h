@@ -147,7 +147,9 @@ struct EnvLoad {
     float obs;
 };
 
-__device__ __forceinline__ EnvLoad load_env_issue(const DevState &S, int env)
+// (with_keys = false: the candidate keys and stamps stay in HBM -- only a step that extracts an element reads them (the
+// candidate patch of env_apply and the selection that follows), see load_keys)
+__device__ __forceinline__ EnvLoad load_env_issue(const DevState &S, int env, const bool with_keys = true)
 {
     EnvLoad L;
     const int lane = lane_id();
@@ -167,8 +169,10 @@ __device__ __forceinline__ EnvLoad load_env_issue(const DevState &S, int env)
     if (lane < first) {
         L.v_xy = gxy[ul];
         L.v_id = gid[ul];
-        L.v_key = gkey[ul];
-        L.v_st = gst[ul];
+        if (with_keys) {
+            L.v_key = gkey[ul];
+            L.v_st = gst[ul];
+        }
     }
     // rings longer than 64: the second chunk is requested in the same burst, up to the ring STRIDE (known from the
     // kernel arguments) rather than the ring length (known only once the record has arrived) -- no second round trip
@@ -176,14 +180,16 @@ __device__ __forceinline__ EnvLoad load_env_issue(const DevState &S, int env)
     if (second) {
         L.w_xy = gxy[64u + ul];
         L.w_id = gid[64u + ul];
-        L.w_key = gkey[64u + ul];
-        L.w_st = gst[64u + ul];
+        if (with_keys) {
+            L.w_key = gkey[64u + ul];
+            L.w_st = gst[64u + ul];
+        }
     }
     L.obs = lane < kObsDim ? S.obs_cache[(size_t)env * kObsDim + lane] : 0.0f;
     return L;
 }
 
-__device__ __forceinline__ void load_env_commit(Ctx &c, const DevState &S, int env, const EnvLoad &L)
+__device__ __forceinline__ void load_env_commit(Ctx &c, const DevState &S, int env, const EnvLoad &L, const bool with_keys = true)
 {
     const int lane = lane_id();
     c.lane = lane;
@@ -206,28 +212,46 @@ __device__ __forceinline__ void load_env_commit(Ctx &c, const DevState &S, int e
     if (lane < first) {
         c.xy[lane] = L.v_xy;
         c.id[lane] = L.v_id;
-        c.key[lane] = L.v_key;
-        c.stamp[lane] = L.v_st;
+        if (with_keys) {
+            c.key[lane] = L.v_key;
+            c.stamp[lane] = L.v_st;
+        }
     }
     if (second) {
         c.xy[64u + ul] = L.w_xy;
         c.id[64u + ul] = L.w_id;
-        c.key[64u + ul] = L.w_key;
-        c.stamp[64u + ul] = L.w_st;
+        if (with_keys) {
+            c.key[64u + ul] = L.w_key;
+            c.stamp[64u + ul] = L.w_st;
+        }
     }
     for (unsigned i = 128u + ul; i < (unsigned)c.n; i += 64u) {
         c.xy[i] = gxy[i];
         c.id[i] = gid[i];
-        c.key[i] = gkey[i];
-        c.stamp[i] = gst[i];
+        if (with_keys) {
+            c.key[i] = gkey[i];
+            c.stamp[i] = gst[i];
+        }
     }
     wave_sync();
 }
 
-__device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env)
+__device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env, const bool with_keys = true)
 {
-    const EnvLoad L = load_env_issue(S, env);
-    load_env_commit(c, S, env, L);
+    const EnvLoad L = load_env_issue(S, env, with_keys);
+    load_env_commit(c, S, env, L, with_keys);
+}
+
+// the candidate keys and stamps of a ring staged without them (load_env(.., false)), before an extraction
+__device__ __forceinline__ void load_keys(Ctx &c, const DevState &S)
+{
+    const double *gkey = S.ring_key + c.base;
+    const int32_t *gst = S.ring_stamp + c.base;
+    for (unsigned i = (unsigned)c.lane; i < (unsigned)c.n; i += 64u) {
+        c.key[i] = gkey[i];
+        c.stamp[i] = gst[i];
+    }
+    wave_sync();
 }
 
 // ring arrays LDS -> HBM (slots [0, n))
@@ -1641,11 +1665,15 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
             return;
         }
     }
+    // (same regime: the ring is staged without its candidate keys / stamps -- 12 of 32 B per slot -- which only the 11 % of
+    // steps that extract an element read; those fetch them behind one more round trip, hidden like the one above)
+    const bool light = !kMulti && (auto_reset & 4) != 0;
     auto_reset &= 1;
 #ifndef MESHENV_STAMPS
     const EnvCounters cnt0 = S.cnt[env];  // requested with the rest of the state: no round trip at the end
 #endif
-    load_env(c, S, env);
+    if (light) load_env(c, S, env, false);
+    else load_env(c, S, env);
 #ifdef MESHENV_STAMPS
     const unsigned long long stamp_t1 = __builtin_amdgcn_s_memrealtime();
     if (c.lane < 16) c.sc->stamps[c.lane] = 0;
@@ -1671,7 +1699,13 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
             a0 = at[0]; a1 = at[1]; a2 = at[2];
         }
         const int n_before = c.n;
-        const StepResult r = env_step(c, S, a0, a1, a2, kMulti);
+        // env_step, with the keys of a ring staged without them fetched between the checks and the update
+        Decision d = env_check(c, S, a0, a1, a2, kMulti);
+        if (d.ok) {
+            if (light) load_keys(c, S);
+            env_apply(c, S, d);
+        }
+        const StepResult r = env_finish(c, S.prm, d);
 #ifdef MESHENV_STAMPS
         if (r.valid) st_valid += 1;
 #else

@@ -270,8 +270,10 @@ def test_record_first_staging_equals_full_staging(torch_cuda, monkeypatch):
     for t in range(T):
         a = (lo + (hi - lo) * torch.rand((n, 3), device="cuda", generator=g)).contiguous()
         monkeypatch.setenv("MESHENV_LAZY", "0")
+        monkeypatch.setenv("MESHENV_LIGHT", "0")
         o1, r1, d1, c1 = [x.clone() for x in full.step(a)]
         monkeypatch.setenv("MESHENV_LAZY", "1")
+        monkeypatch.setenv("MESHENV_LIGHT", "1")       # ... and the ring staged without its candidate keys / stamps
         o2, r2, d2, c2 = lazy.step(a)
         assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(c1, c2), t
         truncated += int(((d1 != 0) & (c1 == 0)).sum())
