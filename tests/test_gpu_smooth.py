@@ -437,3 +437,33 @@ def test_fused_rollout_continues_from_a_front_smoothed_state(torch_cuda):
         assert np.abs(rew[t].cpu().numpy() - r_ref).max() <= 1e-5, t
     assert np.abs(obs.cpu().numpy().astype(np.float64) - o_ref).max() <= 1e-5
     env.close()
+
+
+def test_single_env_surface_post_processing_like_ebrd(torch_cuda):
+    """The reference's post-processing (general/EBRD.py:389-393) through the drop-in class: run an episode to its end, then
+    `env.smooth(...)` if the front is down to <= 5 vertices, else `env.smooth_pave(..., interior=True)`; checked against the
+    recorded reference calls of the fixture (sweep counts and vertex tables)."""
+    from reinforcementlearning4meshgeneration_amd import BoudaryEnv
+    tr = dict(np.load(os.path.join(GOLDEN_DIR, "smoothfinal_star_s6.npz")))
+    env = BoudaryEnv([tuple(p) for p in tr["domain_xy"]])
+    env.reset()
+    calls = {int(t): k for k, t in enumerate(tr["call_t"])}
+    done_calls = 0
+    for t, a in enumerate(tr["actions"]):
+        obs, rew, done, info = env.step(a)
+        assert done == bool(tr["done"][t]) and info["is_complete"] == bool(tr["complete"][t])
+        if t in calls:
+            k = calls[t]
+            nv = int(tr["call_nv"][k])
+            sweeps = env.smooth(None, iteration=int(tr["iteration"]))
+            assert sweeps == int(tr["call_sweeps"][k])
+            assert np.abs(env._vec.get_elements(0)[1] - tr["call_after"][k, :nv]).max() <= 1e-11
+            done_calls += 1
+        elif done and not info["is_complete"]:
+            assert env.smooth_pave(None, None, iteration=50, interior=True) >= 1      # an unfinished mesh: interior pass
+        if done:
+            env.reset()
+    assert done_calls >= 5
+    with pytest.raises(RuntimeError):
+        env.smooth()          # a running episode (front > 5) is not a finished mesh
+    env.close()
