@@ -8,11 +8,12 @@
 // and the rollout loop stays at two launches per vector step.
 //
 // GEMM-shaped, so it runs on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate -- bit-for-bit a
-// k-ordered fmaf chain, no reduced precision).  16 environments per 256-thread workgroup (4096 envs -> 256 workgroups,
-// one per CU); wave w owns neurons [32w, 32w + 32) as two 16x16 accumulator tiles (two independent chains cover the
-// 40-cycle dependent MFMA latency).  The B operand (weights) of a whole layer lives in registers: 64 floats per lane,
-// packed on the host in exactly the per-lane order so that a wave loads them with sixteen coalesced 1 KB requests,
-// issued one layer ahead of their use.  The A operand (activations) goes through LDS in a k-permuted layout
+// fmaf chain, no reduced precision).  16 environments per 512-thread workgroup (4096 envs -> 256 workgroups, one per
+// CU, eight wavefronts = two per SIMD); wave w owns neurons [16w, 16w + 16) as ONE 16x16 output tile whose k-loop is
+// split over two accumulators (even / odd k-groups, summed at the end: two independent chains cover the 40-cycle
+// dependent MFMA latency).  The B operand (weights) of a whole layer lives in registers: 32 floats per lane, packed on
+// the host in exactly the per-lane order so that a wave loads them with eight coalesced 1 KB requests, issued one layer
+// ahead of their use.  (Four waves with two tiles each: 8.5 us per launch; eight waves: measured in DESIGN.md section 7.)  The A operand (activations) goes through LDS in a k-permuted layout
 // ([env][k & 3][k >> 2], row stride 132 floats) so that one conflict-free ds_read_b128 feeds four MFMA k-steps.
 #pragma once
 
@@ -28,8 +29,8 @@ constexpr int kActStride = 132; // LDS row stride in floats: 132 mod 64 = 4 -> 1
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Packed weight of a layer with K inputs: [wave 4][tile 2][K/16][lane 64][4]; element j of lane l in group g is
-// W[k = 4 * (4 g + j) + (l >> 4)][n = 32 wave + 16 tile + (l & 15)]  (meshenv_actor_load builds it).
+// Packed weight of a layer with K inputs: [tile 8][K/16][lane 64][4] (tile = wave); element j of lane l in group g is
+// W[k = 4 * (4 g + j) + (l >> 4)][n = 16 tile + (l & 15)]  (meshenv_actor_load builds it).
 struct ActorWeights {
     const float *w1p, *b1;  // K = 32 (18 padded), [128]
     const float *w2p, *b2;  // K = 128
@@ -68,22 +69,22 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t counter, 
     return rad * (which == 1 ? sn : cs);
 }
 
+constexpr int kActWaves = 8;    // wavefronts per workgroup = 16-neuron output tiles of a hidden layer
+
 template <int G>  // G = K / 16 float4 groups per tile
 struct LayerRegs {
-    f32x4 w[2][G];
+    f32x4 w[G];
 };
 
 template <int G>
 __device__ __forceinline__ void load_layer(LayerRegs<G> &r, const float *__restrict__ wp, int wave, int lane)
 {
 #pragma unroll
-    for (int tile = 0; tile < 2; tile++)
-#pragma unroll
-        for (int g = 0; g < G; g++)
-            r.w[tile][g] = *reinterpret_cast<const f32x4 *>(wp + ((((size_t)wave * 2 + tile) * G + g) * 64 + lane) * 4);
+    for (int g = 0; g < G; g++)
+        r.w[g] = *reinterpret_cast<const f32x4 *>(wp + (((size_t)wave * G + g) * 64 + lane) * 4);
 }
 
-// y = relu(W x + b) for the wave's 32 neurons; x: LDS [16][kActStride] in the permuted layout of a K-input layer
+// y = relu(W x + b) for the wave's 16 neurons; x: LDS [16][kActStride] in the permuted layout of a K-input layer
 // (position (k & 3) * (K / 4) + (k >> 2)); y: the 128-input layout of the next layer
 template <int G>
 __device__ __forceinline__ void actor_layer(const LayerRegs<G> &r, const float *__restrict__ bias, const float *x, float *y,
@@ -93,27 +94,27 @@ __device__ __forceinline__ void actor_layer(const LayerRegs<G> &r, const float *
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const float *xr = x + e * kActStride + q * (4 * G);
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 4 * g);
+    for (int g = 0; g < G; g += 2) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(xr + 4 * g);
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(xr + 4 * g + 4);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], r.w[0][g][j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], r.w[1][g][j], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], r.w[g][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], r.w[g + 1][j], acc1, 0, 0, 0);
         }
     }
     // D[row = 4 (lane >> 4) + reg][col = lane & 15]
-    const int n0 = 32 * wave + e, n1 = n0 + 16;
-    const float b0 = bias[n0], b1 = bias[n1];
-    const int p0 = (n0 & 3) * 32 + (n0 >> 2), p1 = (n1 & 3) * 32 + (n1 >> 2);
+    const int n0 = 16 * wave + e;
+    const float b0 = bias[n0];
+    const int p0 = (n0 & 3) * 32 + (n0 >> 2);
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
         float *row = y + (4 * q + reg) * kActStride;
-        row[p0] = fmaxf(acc0[reg] + b0, 0.0f);
-        row[p1] = fmaxf(acc1[reg] + b1, 0.0f);
+        row[p0] = fmaxf((acc0[reg] + acc1[reg]) + b0, 0.0f);
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * kActWaves)
 k_actor_forward(ActorWeights W, int n, const float *__restrict__ obs, const float *__restrict__ noise,
                 float *__restrict__ actions, int sample, uint64_t seed, uint64_t counter, float *__restrict__ eps_out)
 {
@@ -126,23 +127,24 @@ k_actor_forward(ActorWeights W, int n, const float *__restrict__ obs, const floa
     LayerRegs<8> r2, r3;
     load_layer<2>(r1, W.w1p, wave, lane);
     load_layer<8>(r2, W.w2p, wave, lane);
+
     // exploration noise, drawn while the weights are in flight: wave w draws row 4 q + w of every 4-row group
     __shared__ float eps_lds[kActEnvs * 4];
-    if ((lane & 15) < kActOut && (noise || sample)) {
+    if (wave < 4 && (lane & 15) < kActOut && (noise || sample)) {
         const int row = 4 * (lane >> 4) + wave, env = env0 + row;
         float eps = 0.0f;
         if (env < n) eps = sample ? philox_normal(seed, counter, (uint32_t)env, lane & 15) : noise[(size_t)env * 3 + (lane & 15)];
         eps_lds[row * 4 + (lane & 15)] = eps;
     }
     // observations -> bufA in the K = 32 layout (zero for k >= 18 and for envs past n)
-    for (int i = t; i < kActEnvs * kActInPad; i += 256) {
+    for (int i = t; i < kActEnvs * kActInPad; i += 64 * kActWaves) {
         const int e = i >> 5, k = i & 31;
         const float v = (k < kActIn && env0 + e < n) ? obs[(size_t)(env0 + e) * kActIn + k] : 0.0f;
         bufA[e * kActStride + (k & 3) * (kActInPad / 4) + (k >> 2)] = v;
     }
     __syncthreads();
     actor_layer<2>(r1, W.b1, bufA, bufB, wave, lane);
-    load_layer<8>(r3, W.w3p, wave, lane);
+    load_layer<8>(r3, W.w3p, wave, lane);   // (requesting all three layers up front measured 8.27 against 8.11 us)
     __syncthreads();
     actor_layer<8>(r2, W.b2, bufB, bufA, wave, lane);
     f32x4 wh[8];

@@ -1155,7 +1155,7 @@ int meshenv_actor_load(MeshActor *a, const float *w1, const float *b1, const flo
     if (!a || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w_mu || !b_mu || !w_log_std || !b_log_std || !low || !high)
         return MESHENV_E_ARG;
     std::vector<float> h;
-    // torch [out][in] -> the per-lane MFMA B-operand order of meshenv_actor.h: [wave][tile][K/16][lane][4]
+    // torch [out][in] -> the per-lane MFMA B-operand order of meshenv_actor.h: [16-neuron tile = 2 wv + tile][K/16][lane][4]
     auto packed = [&](const float *w, int out, int in, int k_pad, int waves) {
         const size_t off = h.size();
         const int groups = k_pad / 16;
@@ -1228,7 +1228,7 @@ static int actor_launch(MeshActor *a, const char *fn, int n, const float *obs_de
         a->err = std::string(fn) + ": hipSetDevice failed";
         return MESHENV_E_HIP;
     }
-    hipLaunchKernelGGL(k_actor_forward, dim3((n + kActEnvs - 1) / kActEnvs), dim3(256), 0, a->stream, a->W, n, obs_dev, noise_dev,
+    hipLaunchKernelGGL(k_actor_forward, dim3((n + kActEnvs - 1) / kActEnvs), dim3(64 * kActWaves), 0, a->stream, a->W, n, obs_dev, noise_dev,
                        actions_dev, sample, seed, counter, eps_out_dev);
     if (hipGetLastError() != hipSuccess) {
         a->err = std::string(fn) + ": launch failed";
