@@ -27,8 +27,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--domain", default="d1", choices=["d1", "boundary0"])
     ap.add_argument("--deterministic", action="store_true")
-    ap.add_argument("--actor", default="fused", choices=["fused", "fused-ext-noise", "graph", "eager"],
-                    help="fused = the hand-written HIP actor kernel, exploration noise drawn inside it (one launch); "
+    ap.add_argument("--actor", default="fused", choices=["one-launch", "fused", "fused-ext-noise", "graph", "eager"],
+                    help="one-launch = env step + actor forward in ONE kernel per vector step (meshenv_step_actor); "
+                         "fused = the hand-written HIP actor kernel, exploration noise drawn inside it (one launch); "
                          "fused-ext-noise = same kernel fed by torch's normal_() (two launches); graph = the torch MLP captured as one HIP "
                          "graph; eager = the torch MLP launch by launch")
     args = ap.parse_args()
@@ -62,7 +63,7 @@ def main():
 
     env = MeshVecEnv([dom], n_envs=args.envs, device=0)
     obs = env.reset()          # env.obs: the kernel always writes observations into this tensor
-    if args.actor.startswith("fused"):
+    if args.actor.startswith("fused") or args.actor == "one-launch":
         from reinforcementlearning4meshgeneration_amd.actor import FusedActor
         fused = FusedActor.from_torch([trunk[0], trunk[2], trunk[4]], mu_head, log_std_head)
         actions = torch.empty((args.envs, 3), dtype=torch.float32, device=dev)
@@ -72,7 +73,7 @@ def main():
         def policy(o):
             if args.deterministic:
                 return fused.forward(o, None, out=actions)
-            if args.actor == "fused":
+            if args.actor in ("fused", "one-launch"):
                 draw[0] += 1
                 return fused.sample(o, 999, draw[0], out=actions)
             return fused.forward(o, noise.normal_(), out=actions)
@@ -93,13 +94,23 @@ def main():
             return static_act
     else:
         policy = act
-    # timed loop: policy + step only (two or three launches per vector step)
-    for t in range(args.warmup + args.steps):
-        if t == args.warmup:
-            torch.cuda.synchronize()
-            c0 = env.counters()
-            t0 = time.perf_counter()
-        obs, rew, done, comp = env.step(policy(obs))
+    # timed loop: policy + step only (one, two or three launches per vector step)
+    if args.actor == "one-launch":
+        nxt = policy(obs)
+        for t in range(args.warmup + args.steps):
+            if t == args.warmup:
+                torch.cuda.synchronize()
+                c0 = env.counters()
+                t0 = time.perf_counter()
+            draw[0] += 1
+            obs, rew, done, comp, nxt = env.step_actor(fused, nxt, seed=999, counter=draw[0], sample=not args.deterministic)
+    else:
+        for t in range(args.warmup + args.steps):
+            if t == args.warmup:
+                torch.cuda.synchronize()
+                c0 = env.counters()
+                t0 = time.perf_counter()
+            obs, rew, done, comp = env.step(policy(obs))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c1 = env.counters()

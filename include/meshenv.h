@@ -388,6 +388,18 @@ int meshenv_actor_forward(MeshActor *a, int n, const float *obs_dev, const float
 int meshenv_actor_sample(MeshActor *a, int n, const float *obs_dev, uint64_t seed, uint64_t counter, float *actions_dev,
                          float *eps_out_dev);
 
+/* One launch per vector step of the closed RL loop: meshenv_step(actions_dev, ...) followed by meshenv_actor_sample /
+ * meshenv_actor_forward on the observations it produced -- i.e. obs_dev, reward_dev, done_dev, complete_dev,
+ * terminal_obs_dev exactly as meshenv_step writes them, and actions_next_dev [n_envs][3] = the policy's actions for the
+ * NEXT step (sample != 0: SAC's stochastic actor with in-kernel Philox noise keyed by (seed, counter), eps_out_dev nullable;
+ * sample == 0: the mean action).  actions_next_dev must not alias actions_dev (ping-pong two buffers).  When the batch runs
+ * on the CU-group kernel (256 * 16 envs, default parameters) and env and actor share device and stream, both halves run
+ * in ONE kernel (csrc/meshenv_fused.h: the same 16 envs per workgroup, the actor's forward after the step's barrier);
+ * otherwise two launches are issued.  Results are identical either way. */
+int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float *obs_dev, double *reward_dev, uint8_t *done_dev,
+                       uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset, int sample, uint64_t seed, uint64_t counter,
+                       float *actions_next_dev, float *eps_out_dev);
+
 /*
  * Test hook: evaluate one device geometry primitive on n items (in_per_item doubles each) and copy the results
  * back, so the parity tests can compare the device primitives with the oracle's one by one.

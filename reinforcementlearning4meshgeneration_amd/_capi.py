@@ -41,7 +41,7 @@ EXPORTS = [
     "meshenv_actor_create", "meshenv_actor_destroy", "meshenv_actor_set_stream", "meshenv_actor_load",
     "meshenv_actor_forward", "meshenv_actor_sample", "meshenv_get_last_episode", "meshenv_element_quality",
     "meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid", "meshenv_step_kernel",
-    "meshenv_create_random", "meshenv_get_domain", "meshenv_smooth", "meshenv_smooth_final", "meshenv_get_not_valid_ids",
+    "meshenv_create_random", "meshenv_get_domain", "meshenv_smooth", "meshenv_smooth_final", "meshenv_get_not_valid_ids", "meshenv_step_actor",
 ]
 
 
@@ -99,6 +99,8 @@ def load():
     L.meshenv_get_not_valid.argtypes = [vp, C.c_int, vp, C.c_int, i32p]
     L.meshenv_get_not_valid_ids.argtypes = [vp, C.c_int, vp, C.c_int, i32p, vp]
     L.meshenv_get_not_valid_ids.restype = C.c_int
+    L.meshenv_step_actor.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_uint64, C.c_uint64, vp, vp]
+    L.meshenv_step_actor.restype = C.c_int
     L.meshenv_smooth.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.meshenv_smooth.restype = C.c_int
     L.meshenv_smooth_final.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, C.c_double, vp, vp]

@@ -114,22 +114,28 @@ __device__ __forceinline__ void actor_layer(const LayerRegs<G> &r, const float *
     }
 }
 
-__global__ void __launch_bounds__(64 * kActWaves)
-k_actor_forward(ActorWeights W, int n, const float *__restrict__ obs, const float *__restrict__ noise,
-                float *__restrict__ actions, int sample, uint64_t seed, uint64_t counter, float *__restrict__ eps_out)
+// LDS of one actor tile: two activation buffers + the exploration noise
+constexpr int kActorLdsFloats = 2 * kActEnvs * kActStride + kActEnvs * 4;
+
+// The forward of the 16 envs env0 .. env0 + 15 by the first kActWaves wavefronts of a workgroup (`t` = thread index in the
+// workgroup; every thread of the workgroup must call: the function contains workgroup barriers, wavefronts past
+// kActWaves only take part in those).  lds: kActorLdsFloats floats, 16-byte aligned.
+__device__ __forceinline__ void actor_forward_tile(const ActorWeights &W, int n, int env0, const float *__restrict__ obs,
+                                                   const float *__restrict__ noise, float *__restrict__ actions, int sample,
+                                                   uint64_t seed, uint64_t counter, float *__restrict__ eps_out, float *lds, int t,
+                                                   int n_threads)
 {
-    __shared__ __attribute__((aligned(16))) float bufA[kActEnvs * kActStride];
-    __shared__ __attribute__((aligned(16))) float bufB[kActEnvs * kActStride];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int env0 = blockIdx.x * kActEnvs;
+    float *bufA = lds, *bufB = lds + kActEnvs * kActStride, *eps_lds = lds + 2 * kActEnvs * kActStride;
+    const int lane = t & 63, wave = t >> 6;
+    const bool worker = wave < kActWaves;
 
     LayerRegs<2> r1;
     LayerRegs<8> r2, r3;
-    load_layer<2>(r1, W.w1p, wave, lane);
-    load_layer<8>(r2, W.w2p, wave, lane);
-
+    if (worker) {
+        load_layer<2>(r1, W.w1p, wave, lane);
+        load_layer<8>(r2, W.w2p, wave, lane);
+    }
     // exploration noise, drawn while the weights are in flight: wave w draws row 4 q + w of every 4-row group
-    __shared__ float eps_lds[kActEnvs * 4];
     if (wave < 4 && (lane & 15) < kActOut && (noise || sample)) {
         const int row = 4 * (lane >> 4) + wave, env = env0 + row;
         float eps = 0.0f;
@@ -137,23 +143,25 @@ k_actor_forward(ActorWeights W, int n, const float *__restrict__ obs, const floa
         eps_lds[row * 4 + (lane & 15)] = eps;
     }
     // observations -> bufA in the K = 32 layout (zero for k >= 18 and for envs past n)
-    for (int i = t; i < kActEnvs * kActInPad; i += 64 * kActWaves) {
+    for (int i = t; i < kActEnvs * kActInPad; i += n_threads) {
         const int e = i >> 5, k = i & 31;
         const float v = (k < kActIn && env0 + e < n) ? obs[(size_t)(env0 + e) * kActIn + k] : 0.0f;
         bufA[e * kActStride + (k & 3) * (kActInPad / 4) + (k >> 2)] = v;
     }
     __syncthreads();
-    actor_layer<2>(r1, W.b1, bufA, bufB, wave, lane);
-    load_layer<8>(r3, W.w3p, wave, lane);   // (requesting all three layers up front measured 8.27 against 8.11 us)
+    if (worker) {
+        actor_layer<2>(r1, W.b1, bufA, bufB, wave, lane);
+        load_layer<8>(r3, W.w3p, wave, lane);   // (requesting all three layers up front measured 8.27 against 8.11 us)
+    }
     __syncthreads();
-    actor_layer<8>(r2, W.b2, bufB, bufA, wave, lane);
+    if (worker) actor_layer<8>(r2, W.b2, bufB, bufA, wave, lane);
     f32x4 wh[8];
     if (wave == 0) {
 #pragma unroll
         for (int g = 0; g < 8; g++) wh[g] = *reinterpret_cast<const f32x4 *>(W.whp + ((size_t)g * 64 + lane) * 4);
     }
     __syncthreads();
-    actor_layer<8>(r3, W.b3, bufA, bufB, wave, lane);
+    if (worker) actor_layer<8>(r3, W.b3, bufA, bufB, wave, lane);
     __syncthreads();
     if (wave != 0) return;
     // heads on wave 0: one 16-wide tile, two accumulators over even / odd k-groups
@@ -189,6 +197,15 @@ k_actor_forward(ActorWeights W, int n, const float *__restrict__ obs, const floa
             actions[(size_t)env * 3 + e] = W.low[e] + 0.5f * (sq + 1.0f) * (W.high[e] - W.low[e]);
         }
     }
+}
+
+__global__ void __launch_bounds__(64 * kActWaves)
+k_actor_forward(ActorWeights W, int n, const float *__restrict__ obs, const float *__restrict__ noise,
+                float *__restrict__ actions, int sample, uint64_t seed, uint64_t counter, float *__restrict__ eps_out)
+{
+    __shared__ __attribute__((aligned(16))) float lds[kActorLdsFloats];
+    actor_forward_tile(W, n, blockIdx.x * kActEnvs, obs, noise, actions, sample, seed, counter, eps_out, lds, threadIdx.x,
+                       64 * kActWaves);
 }
 
 }  // namespace meshenv

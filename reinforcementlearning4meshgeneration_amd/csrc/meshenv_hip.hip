@@ -19,6 +19,7 @@
 #include "meshenv_kernels.h"
 #include "meshenv_quality.h"
 #include "meshenv_smooth.h"
+#include "meshenv_fused.h"
 
 using namespace meshenv;
 
@@ -51,6 +52,7 @@ struct MeshEnv {
     float *pend_obs = nullptr;         // [E][18]
     bool reselect_pending = false;     // a rebuild ran since the last step kernel
     bool smooth_final_ready = false;
+    bool fused_ready = false;          // k_step_group_actor's LDS attribute set
     // move() API state, allocated by the first meshenv_move: not_valid_points per env
     double2 *nv_xy = nullptr;    // [E][cap]
     int32_t *nv_count = nullptr; // [E]
@@ -1246,6 +1248,52 @@ int meshenv_actor_sample(MeshActor *a, int n, const float *obs_dev, uint64_t see
                          float *eps_out_dev)
 {
     return actor_launch(a, "meshenv_actor_sample", n, obs_dev, nullptr, actions_dev, 1, seed, counter, eps_out_dev);
+}
+
+int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float *obs_dev, double *reward_dev, uint8_t *done_dev,
+                       uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset, int sample, uint64_t seed, uint64_t counter,
+                       float *actions_next_dev, float *eps_out_dev)
+{
+    if (!h || !a) return MESHENV_E_ARG;
+    if (!actions_dev || !obs_dev || !reward_dev || !done_dev || !complete_dev || !actions_next_dev || actions_next_dev == actions_dev)
+        return fail_arg(h, "meshenv_step_actor: null device pointer, or actions_next aliases actions");
+    if (!a->loaded) {
+        h->err = "meshenv_step_actor: the actor has no weights loaded";
+        return MESHENV_E_STATE;
+    }
+    const bool fusable = h->group == 16 && !h->spec && h->default_params && a->device == h->device && a->stream == h->stream &&
+                         h->timing == 0 && !h->reselect_pending && group_actor_lds_bytes(h->cap) <= 160 * 1024;
+    if (!fusable) {   // same results by two launches (other batch sizes / ring lengths, separate streams, timing armed, the
+                      // step after meshenv_smooth whose parked re-selection changes the observation the policy reads)
+        const int rc = launch_step(h, 1, actions_dev, obs_dev, reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
+        if (rc != MESHENV_OK) return rc;
+        const int ra = actor_launch(a, "meshenv_step_actor", h->n_envs, obs_dev, nullptr, actions_next_dev, sample, seed, counter,
+                                    eps_out_dev);
+        if (ra != MESHENV_OK) h->err = a->err;
+        return ra;
+    }
+    MESHENV_ON_DEVICE(h);
+    if (!h->fused_ready) {
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_step_group_actor<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        h->fused_ready = true;
+    }
+    GroupActorArgs GA;
+    GA.g.S = h->S;
+    GA.g.outs.obs_out = obs_dev; GA.g.outs.reward = reward_dev; GA.g.outs.done = done_dev; GA.g.outs.complete = complete_dev;
+    GA.g.outs.term_obs = terminal_obs_dev;
+    GA.g.actions = actions_dev;
+    GA.g.step0 = (unsigned long long)h->steps_done;
+    GA.g.cap = h->cap;
+    GA.g.auto_reset = auto_reset;
+    GA.W = a->W;
+    GA.actions_next = actions_next_dev;
+    GA.eps_out = eps_out_dev;
+    GA.seed = seed; GA.counter = counter;
+    GA.sample = sample ? 1 : 0; GA.pad = 0;
+    hipLaunchKernelGGL((k_step_group_actor<true>), dim3((h->n_envs + 15) / 16), dim3(64 * 16), group_actor_lds_bytes(h->cap), h->stream, GA);
+    HIP_TRY(h, hipGetLastError());
+    h->steps_done += 1;
+    return MESHENV_OK;
 }
 
 }  // extern "C"

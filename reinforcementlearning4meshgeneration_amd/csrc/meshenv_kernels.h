@@ -1936,9 +1936,9 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
 // UPDATES are dealt round-robin over the four SIMDs of the CU (phase 2): wave (simd s, r-th on that SIMD) takes the
 // (4r+s)-th pending env of the group.  The env's ring never moves -- it is already in the workgroup's LDS -- only
 // ~40 scalars are handed over (Handoff).  Environments stay independent: no data is shared between envs.
+// (the body as a function: k_step_group is just this; k_step_group_actor, csrc/meshenv_fused.h, appends the policy's forward)
 template <int G, bool kDefaultParams>
-__global__ void __launch_bounds__(64 * G)
-k_step_group(GroupArgs A)
+__device__ __forceinline__ void step_group_body(const GroupArgs &A)
 {
     extern __shared__ double2 smem[];
     DevState S = A.S;
@@ -2120,6 +2120,13 @@ k_step_group(GroupArgs A)
 #endif
 }
 
+
+template <int G, bool kDefaultParams>
+__global__ void __launch_bounds__(64 * G)
+k_step_group(GroupArgs A)
+{
+    step_group_body<G, kDefaultParams>(A);
+}
 
 // ------------------------------------------------------------------------------------------ speculative CU-group kernel
 

@@ -367,6 +367,32 @@ class MeshVecEnv:
         self._check(rc, "meshenv_step")
         return self.obs, self.reward, self.done, self.complete
 
+    def step_actor(self, actor, actions, seed: int = 0, counter: int = 0, sample: bool = True, eps_out=None):
+        """One step() of every env AND the policy's actions for the next one, in one launch where the batch runs on the
+        CU-group kernel (two launches otherwise; identical results): `actor` is a FusedActor on this device.
+        Returns (obs, reward, done, complete, next_actions); next_actions is one of two internal ping-pong buffers, valid
+        until the call after next -- pass it straight back as `actions`."""
+        t = self._torch
+        if actions.dtype != t.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=t.float32).contiguous()
+        if actions.shape != (self.num_envs, 3):
+            raise ValueError(f"actions must have shape ({self.num_envs}, 3), got {tuple(actions.shape)}")
+        if not hasattr(self, "_act_pp"):
+            self._act_pp = [t.empty((self.num_envs, 3), dtype=t.float32, device=self.device) for _ in range(2)]
+        nxt = self._act_pp[0] if actions.data_ptr() != self._act_pp[0].data_ptr() else self._act_pp[1]
+        self._bind_stream()
+        stream = t.cuda.current_stream(self.device).cuda_stream
+        if stream != actor._stream:
+            actor._L.meshenv_actor_set_stream(actor._h, C.c_void_p(stream))
+            actor._stream = stream
+        rc = self._L.meshenv_step_actor(self._handle, actor._h, actions.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
+                                        self.done.data_ptr(), self.complete.data_ptr(), self.terminal_obs.data_ptr(),
+                                        1 if self.auto_reset else 0, 1 if sample else 0, C.c_uint64(seed & (2 ** 64 - 1)),
+                                        C.c_uint64(counter & (2 ** 64 - 1)), nxt.data_ptr(),
+                                        eps_out.data_ptr() if eps_out is not None else None)
+        self._check(rc, "meshenv_step_actor")
+        return self.obs, self.reward, self.done, self.complete, nxt
+
     def rollout(self, actions):
         """T consecutive steps in one kernel launch.  actions: float32 CUDA tensor [T, n, 3].
         Returns (obs_after_last_step [n,18], reward [T,n], done [T,n], complete [T,n])."""

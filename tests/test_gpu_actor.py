@@ -76,3 +76,42 @@ def test_in_kernel_noise_is_reproducible_and_standard_normal():
     assert np.abs(c - np.eye(6)).max() < 0.01
     assert abs(np.corrcoef(e[:-1, 0], e[1:, 0])[0, 1]) < 0.01                        # neighbouring envs
     actor.close()
+
+
+def test_fused_step_and_actor_equals_the_two_launch_path():
+    """meshenv_step_actor: the env step and the SAC actor's forward for the next actions in ONE kernel (the CU-group kernel
+    with the actor appended, csrc/meshenv_fused.h) against meshenv_step + meshenv_actor_sample on a second, identical batch:
+    observations, rewards, flags and next actions bit-identical over 96 closed-loop steps on 4096 d1 envs; and the two-launch
+    fallback of the same entry point (2 048 envs: not the CU-group size) against explicit calls."""
+    import os
+    import torch
+    from conftest import GOLDEN_DIR
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv
+    from reinforcementlearning4meshgeneration_amd.actor import FusedActor
+    torch.manual_seed(7)
+    lin = [torch.nn.Linear(18, 128), torch.nn.Linear(128, 128), torch.nn.Linear(128, 128)]
+    mu, ls = torch.nn.Linear(128, 3), torch.nn.Linear(128, 3)
+    with torch.no_grad():
+        mu.weight.mul_(6.0)
+        ls.bias.fill_(-0.5)
+    actor = FusedActor.from_torch(lin, mu, ls)
+    d1 = [tuple(p) for p in np.load(os.path.join(GOLDEN_DIR, "boundary16_biased_s2.npz"))["domain_xy"]]
+    for n, want_kernel in ((4096, "meshenv::k_step_group<16, true>"), (2048, None)):
+        a_env = MeshVecEnv([d1], n_envs=n)
+        b_env = MeshVecEnv([d1], n_envs=n)
+        if want_kernel:
+            assert a_env.step_kernel == want_kernel
+        obs_a, obs_b = a_env.reset(), b_env.reset()
+        act_a = actor.sample(obs_a, seed=5, counter=0).clone()
+        act_b = act_a.clone()
+        valid = 0
+        for t in range(96):
+            o1, r1, d1f, c1 = [x.clone() for x in a_env.step(act_a)]
+            act_a = actor.sample(o1, seed=5, counter=t + 1).clone()
+            o2, r2, d2f, c2, nxt = b_env.step_actor(actor, act_b, seed=5, counter=t + 1)
+            assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1f, d2f) and torch.equal(c1, c2), (n, t)
+            assert torch.equal(act_a, nxt), (n, t, float((act_a - nxt).abs().max()))
+            act_b = nxt
+        assert a_env.counters() == b_env.counters() and a_env.counters()["valid"] > 0.02 * n * 96
+        a_env.close(); b_env.close()
+    actor.close()
