@@ -117,24 +117,43 @@ __device__ __forceinline__ void actor_layer(const LayerRegs<G> &r, const float *
 // LDS of one actor tile: two activation buffers + the exploration noise
 constexpr int kActorLdsFloats = 2 * kActEnvs * kActStride + kActEnvs * 4;
 
+// the first two layers' weights of a wavefront, requested ahead of the forward (k_step_group_actor: before the barrier
+// that ends the environment step, so that they arrive while the workgroup's slowest wave finishes)
+struct ActorHead {
+    LayerRegs<2> r1;
+    LayerRegs<8> r2;
+    LayerRegs<8> r3;
+    bool have_r3;
+};
+
+// (all3: the third layer as well -- pays where the requester then waits at a barrier anyway, k_step_group_actor; in the
+// standalone kernel one layer ahead is faster: 8.11 against 8.27 us)
+__device__ __forceinline__ void actor_request_weights(ActorHead &hd, const ActorWeights &W, int t, const bool all3 = false)
+{
+    const int lane = t & 63, wave = t >> 6;
+    hd.have_r3 = all3;
+    if (wave < kActWaves) {
+        load_layer<2>(hd.r1, W.w1p, wave, lane);
+        load_layer<8>(hd.r2, W.w2p, wave, lane);
+        if (all3) load_layer<8>(hd.r3, W.w3p, wave, lane);
+    }
+}
+
 // The forward of the 16 envs env0 .. env0 + 15 by the first kActWaves wavefronts of a workgroup (`t` = thread index in the
 // workgroup; every thread of the workgroup must call: the function contains workgroup barriers, wavefronts past
-// kActWaves only take part in those).  lds: kActorLdsFloats floats, 16-byte aligned.
-__device__ __forceinline__ void actor_forward_tile(const ActorWeights &W, int n, int env0, const float *__restrict__ obs,
-                                                   const float *__restrict__ noise, float *__restrict__ actions, int sample,
-                                                   uint64_t seed, uint64_t counter, float *__restrict__ eps_out, float *lds, int t,
-                                                   int n_threads)
+// kActWaves only take part in those).  lds: kActorLdsFloats floats, 16-byte aligned.  obs == nullptr: the first-layer
+// input rows (lds[e * kActStride + (k & 3) * 8 + (k >> 2)], k < 18) were written by the caller; the padding is zeroed here.
+__device__ __forceinline__ void actor_forward_tile(const ActorWeights &W, ActorHead &hd, int n, int env0,
+                                                   const float *__restrict__ obs, const float *__restrict__ noise,
+                                                   float *__restrict__ actions, int sample, uint64_t seed, uint64_t counter,
+                                                   float *__restrict__ eps_out, float *lds, int t, int n_threads)
 {
     float *bufA = lds, *bufB = lds + kActEnvs * kActStride, *eps_lds = lds + 2 * kActEnvs * kActStride;
     const int lane = t & 63, wave = t >> 6;
     const bool worker = wave < kActWaves;
-
-    LayerRegs<2> r1;
-    LayerRegs<8> r2, r3;
-    if (worker) {
-        load_layer<2>(r1, W.w1p, wave, lane);
-        load_layer<8>(r2, W.w2p, wave, lane);
-    }
+    LayerRegs<2> &r1 = hd.r1;
+    LayerRegs<8> &r2 = hd.r2;
+    LayerRegs<8> &r3 = hd.r3;
     // exploration noise, drawn while the weights are in flight: wave w draws row 4 q + w of every 4-row group
     if (wave < 4 && (lane & 15) < kActOut && (noise || sample)) {
         const int row = 4 * (lane >> 4) + wave, env = env0 + row;
@@ -145,13 +164,17 @@ __device__ __forceinline__ void actor_forward_tile(const ActorWeights &W, int n,
     // observations -> bufA in the K = 32 layout (zero for k >= 18 and for envs past n)
     for (int i = t; i < kActEnvs * kActInPad; i += n_threads) {
         const int e = i >> 5, k = i & 31;
-        const float v = (k < kActIn && env0 + e < n) ? obs[(size_t)(env0 + e) * kActIn + k] : 0.0f;
-        bufA[e * kActStride + (k & 3) * (kActInPad / 4) + (k >> 2)] = v;
+        if (obs) {
+            const float v = (k < kActIn && env0 + e < n) ? obs[(size_t)(env0 + e) * kActIn + k] : 0.0f;
+            bufA[e * kActStride + (k & 3) * (kActInPad / 4) + (k >> 2)] = v;
+        } else if (k >= kActIn || env0 + e >= n) {
+            bufA[e * kActStride + (k & 3) * (kActInPad / 4) + (k >> 2)] = 0.0f;
+        }
     }
     __syncthreads();
     if (worker) {
         actor_layer<2>(r1, W.b1, bufA, bufB, wave, lane);
-        load_layer<8>(r3, W.w3p, wave, lane);   // (requesting all three layers up front measured 8.27 against 8.11 us)
+        if (!hd.have_r3) load_layer<8>(r3, W.w3p, wave, lane);   // one layer ahead
     }
     __syncthreads();
     if (worker) actor_layer<8>(r2, W.b2, bufB, bufA, wave, lane);
@@ -204,7 +227,9 @@ k_actor_forward(ActorWeights W, int n, const float *__restrict__ obs, const floa
                 float *__restrict__ actions, int sample, uint64_t seed, uint64_t counter, float *__restrict__ eps_out)
 {
     __shared__ __attribute__((aligned(16))) float lds[kActorLdsFloats];
-    actor_forward_tile(W, n, blockIdx.x * kActEnvs, obs, noise, actions, sample, seed, counter, eps_out, lds, threadIdx.x,
+    ActorHead hd;
+    actor_request_weights(hd, W, threadIdx.x);
+    actor_forward_tile(W, hd, n, blockIdx.x * kActEnvs, obs, noise, actions, sample, seed, counter, eps_out, lds, threadIdx.x,
                        64 * kActWaves);
 }
 

@@ -4,9 +4,9 @@
 // The policy-in-the-loop path is obs -> actor -> actions -> step -> obs: two dependent launches per vector step
 // (k_actor_forward 8.1 us + k_step_group 17.6 us on d1, plus the gap between them).  Both kernels already map 16
 // environments to one workgroup on one CU, so the second can simply continue where the first ends: the workgroup's 16
-// wavefronts run step_group_body (csrc/meshenv_kernels.h), meet at a barrier -- which also orders the observation stores
-// of the workgroup's waves before the loads below -- and its first eight wavefronts run actor_forward_tile
-// (csrc/meshenv_actor.h) on the observations just written, producing the actions of the NEXT step.  Same device functions
+// wavefronts run step_group_body (csrc/meshenv_kernels.h), each leaving the observation its step ends with in the actor's
+// LDS input row as well, request the actor's first weights, meet at a barrier, and the first eight wavefronts run
+// actor_forward_tile (csrc/meshenv_actor.h), producing the actions of the NEXT step.  Same device functions
 // as the two-launch path, so the results are bit-identical to it (tests/test_gpu_actor.py); what is saved is the second
 // kernel's launch ramp and the inter-kernel gap.
 #pragma once
@@ -35,12 +35,14 @@ template <bool kDefaultParams>
 __global__ void __launch_bounds__(64 * 16)
 k_step_group_actor(GroupActorArgs A)
 {
-    step_group_body<16, kDefaultParams>(A.g);   // (returns for every wave: nothing exits before the barrier)
-    __syncthreads();
     extern __shared__ double2 smem[];
     float *lds = (float *)((char *)smem + group_lds_bytes(A.g.cap, 16));
-    const StepOuts o = late_outs();
-    actor_forward_tile(A.W, A.g.S.n_envs, blockIdx.x * kActEnvs, o.obs_out, nullptr, A.actions_next, A.sample, A.seed, A.counter,
+    // every wave writes the observation its step ends with into the actor's input row as well (finish_and_store)
+    step_group_body<16, kDefaultParams>(A.g, lds);   // (returns for every wave: nothing exits before the barrier)
+    ActorHead hd;
+    actor_request_weights(hd, A.W, threadIdx.x, true);   // all three layers: in flight while the workgroup's slowest wave finishes
+    __syncthreads();
+    actor_forward_tile(A.W, hd, A.g.S.n_envs, blockIdx.x * kActEnvs, nullptr, nullptr, A.actions_next, A.sample, A.seed, A.counter,
                        A.eps_out, lds, threadIdx.x, 64 * 16);
 }
 

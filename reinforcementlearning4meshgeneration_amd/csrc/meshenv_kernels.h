@@ -1886,7 +1886,7 @@ __device__ __forceinline__ StepOuts late_outs()
 // an auto-reset waits for it before it overwrites the ring)
 __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, const Decision &d, const EnvCounters &cnt0,
                                                  int n_before, int auto_reset, unsigned long long step0,
-                                                 volatile int *helper_done = nullptr)
+                                                 volatile int *helper_done = nullptr, float *actor_row = nullptr)
 {
     const StepResult r = env_finish(c, S.prm, d);
     const int env = c.env;
@@ -1913,6 +1913,9 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
         }
     }
     if (c.lane < kObsDim) obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
+    // (k_step_group_actor: the same observation straight into the actor's LDS input row, k-permuted as its first layer
+    // reads it -- position (k & 3) * 8 + (k >> 2), csrc/meshenv_actor.h)
+    if (actor_row && c.lane < kObsDim) actor_row[(c.lane & 3) * 8 + (c.lane >> 2)] = c.obs;
     if (S.msg && c.lane < 21 && !(has_helper && c.lane == 18)) {  // the exchange message of the multi-GPU path
         const float v = c.lane < kObsDim ? c.obs : (c.lane == 18 ? (float)r.reward : (c.lane == 19 ? (float)r.done : (float)r.complete));
         S.msg[(size_t)env * 21 + c.lane] = v;
@@ -1937,8 +1940,9 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
 // (4r+s)-th pending env of the group.  The env's ring never moves -- it is already in the workgroup's LDS -- only
 // ~40 scalars are handed over (Handoff).  Environments stay independent: no data is shared between envs.
 // (the body as a function: k_step_group is just this; k_step_group_actor, csrc/meshenv_fused.h, appends the policy's forward)
+// (actor_in: k_step_group_actor only -- LDS [G][132] floats, the actor's first-layer input; nullptr otherwise)
 template <int G, bool kDefaultParams>
-__device__ __forceinline__ void step_group_body(const GroupArgs &A)
+__device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor_in = nullptr)
 {
     extern __shared__ double2 smem[];
     DevState S = A.S;
@@ -1967,7 +1971,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A)
         const int n_before = c.n;
         Decision d = env_check(c, S, a0, a1, a2, false);
         if (!d.ok) {
-            finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0);
+            finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0, nullptr, actor_in ? actor_in + wave * 132 : nullptr);
         } else {
             pending = 1;
             if (c.lane == 0) {
@@ -2104,7 +2108,8 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A)
 #ifdef MESHENV_STAMPS
     const unsigned long long dbg_t8 = __builtin_amdgcn_s_memrealtime();
 #endif
-    finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0, helpers ? &h.helper_done : nullptr);
+    finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0, helpers ? &h.helper_done : nullptr,
+                     actor_in ? actor_in + src * 132 : nullptr);
 #ifdef MESHENV_STAMPS
     if (c.lane == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
