@@ -393,9 +393,10 @@ int meshenv_actor_sample(MeshActor *a, int n, const float *obs_dev, uint64_t see
  * terminal_obs_dev exactly as meshenv_step writes them, and actions_next_dev [n_envs][3] = the policy's actions for the
  * NEXT step (sample != 0: SAC's stochastic actor with in-kernel Philox noise keyed by (seed, counter), eps_out_dev nullable;
  * sample == 0: the mean action).  actions_next_dev must not alias actions_dev (ping-pong two buffers).  When the batch runs
- * on the CU-group kernel (256 * 16 envs, default parameters) and env and actor share device and stream, both halves run
+ * on the CU-group kernel (256 * 16 envs, default parameters) both halves run
  * in ONE kernel (csrc/meshenv_fused.h: the same 16 envs per workgroup, the actor's forward after the step's barrier);
- * otherwise two launches are issued.  Results are identical either way. */
+ * otherwise two launches are issued.  Results are identical either way.  Env and actor must share device and stream
+ * (MESHENV_E_STATE otherwise: the stream is what orders the two halves). */
 int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float *obs_dev, double *reward_dev, uint8_t *done_dev,
                        uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset, int sample, uint64_t seed, uint64_t counter,
                        float *actions_next_dev, float *eps_out_dev);

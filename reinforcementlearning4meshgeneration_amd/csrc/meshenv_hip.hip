@@ -1261,9 +1261,13 @@ int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float
         h->err = "meshenv_step_actor: the actor has no weights loaded";
         return MESHENV_E_STATE;
     }
-    const bool fusable = h->group == 16 && !h->spec && h->default_params && a->device == h->device && a->stream == h->stream &&
+    if (a->device != h->device || a->stream != h->stream) {   // the two halves are ordered by the stream alone
+        h->err = "meshenv_step_actor: env and actor must be on the same device and stream (meshenv_set_stream / meshenv_actor_set_stream)";
+        return MESHENV_E_STATE;
+    }
+    const bool fusable = h->group == 16 && !h->spec && h->default_params &&
                          h->timing == 0 && !h->reselect_pending && group_actor_lds_bytes(h->cap) <= 160 * 1024;
-    if (!fusable) {   // same results by two launches (other batch sizes / ring lengths, separate streams, timing armed, the
+    if (!fusable) {   // same results by two launches (other batch sizes / ring lengths, timing armed, the
                       // step after meshenv_smooth whose parked re-selection changes the observation the policy reads)
         const int rc = launch_step(h, 1, actions_dev, obs_dev, reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset);
         if (rc != MESHENV_OK) return rc;
