@@ -223,7 +223,7 @@ int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, f
  *   Gauss-Seidel relaxation of the generated vertices that are off the front, in boundary.vertices order, until the moved
  *   vertices' coordinate sum changes by <= 0.001 or `iteration` sweeps -- then find_reference_candidates(0)
  *   (general/mesh.py:233-261) on the front.  The front, the reference vertex and the observation are unchanged (as in the
- *   reference), the candidate list is the rebuilt one; the first step after the call must be a meshenv_step (it commits
+ *   reference), the candidate list is the rebuilt one; the first step after the call must be a meshenv_step or meshenv_step_actor, not a meshenv_rollout (it commits
  *   the re-selection the rebuild parked: the reference re-selects at the end of every step, accepted or not).
  *   is_static and obs_dev are ignored.
  * interior == 0 (what move() runs when no reference vertex is selectable, rl/boundary_env.py:405-420):
