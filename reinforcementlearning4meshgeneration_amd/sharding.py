@@ -82,7 +82,10 @@ class BucketExchange:
         self._slot_ptr = [[int(self.buckets[b][k].data_ptr()) for k in range(self.steps)] for b in range(2)]
         self.works = [None, None]      # in-flight collective per bucket
         self.first_step = [None, None]  # first step of the bucket contents handed to that collective
-        self.collectives = 0
+        self.collectives = 0           # collectives issued
+        self.steps_sent = 0            # step messages handed to a collective
+        self._open = None              # (bucket, slots written, first step) of the bucket being filled
+        self._result = [None, None]    # view of gathered[b] the in-flight collective writes
 
     def _bucket(self, t: int) -> int:
         return (t // self.steps) & 1
@@ -93,7 +96,7 @@ class BucketExchange:
             self.works[b] = None
         if self.first_step[b] is not None:
             if self.consumer is not None:
-                self.consumer(self.gathered[b], self.first_step[b])
+                self.consumer(self._result[b], self.first_step[b])
             self.first_step[b] = None
 
     def slot(self, t: int):
@@ -110,20 +113,41 @@ class BucketExchange:
             self._retire(b)
         return self._slot_ptr[b][k]
 
+    def _send(self, b: int, m: int, t0: int):
+        """One collective for the first m slots of bucket b (m == steps: the whole bucket)."""
+        src = self.buckets[b] if m == self.steps else self.buckets[b][:m]
+        dst = self.gathered[b] if m == self.steps else self.gathered[b].view(-1)[: self.world * src.numel()].view(
+            self.world * m, *src.shape[1:])
+        if self.stage_to_cpu:
+            self.dist.all_gather_into_tensor(dst, src.cpu(), group=self.group)
+        else:
+            self.works[b] = self.dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
+        self.first_step[b] = t0
+        self._result[b] = dst
+        self.collectives += 1
+        self.steps_sent += m
+
     def after_step(self, t: int):
         b, k = self._bucket(t), t % self.steps
+        self._open = (b, k + 1, t - k)
         if k != self.steps - 1:
             return
-        if self.stage_to_cpu:
-            self.dist.all_gather_into_tensor(self.gathered[b], self.buckets[b].cpu(), group=self.group)
-        else:
-            self.works[b] = self.dist.all_gather_into_tensor(self.gathered[b], self.buckets[b], group=self.group,
-                                                             async_op=True)
-        self.first_step[b] = t - k
-        self.collectives += 1
+        self._send(b, self.steps, t - k)
+        self._open = None
+
+    def flush(self):
+        """Send the partially filled bucket, if there is one (the consumer then receives ``[world * m, n, 21]`` with
+        m < steps).  A run whose length is not a multiple of ``steps`` ends with this call, so that every step's message
+        is gathered; afterwards ``drain()`` and the next step index may start again at 0."""
+        if self._open is not None:
+            b, m, t0 = self._open
+            self._send(b, m, t0)
+            self._open = None
 
     def drain(self):
-        """Wait for everything in flight (oldest bucket first).  A partially filled bucket is not sent."""
+        """Wait for everything in flight (oldest bucket first).  A partially filled bucket is not sent (``flush()``
+        first if it should be)."""
         order = sorted((b for b in (0, 1) if self.first_step[b] is not None), key=lambda b: self.first_step[b])
         for b in order:
             self._retire(b)
+        self._open = None
