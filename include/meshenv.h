@@ -202,8 +202,10 @@ enum {
     MESHENV_MOVE_NEEDS_SMOOTHING = 3, /* only on handles without a usable element log (log_capacity = 0, overflow, or
                                          too large for the smoother's LDS): the smooth_pave below cannot be run and the
                                          episode ends instead, done = 1, complete = 0 */
-    MESHENV_MOVE_SMOOTH_RAISES = 4    /* a vertex construction inside that smooth_pave is undefined (MESHENV_SMOOTH_RAISES
-                                         below: the reference raises, or goes on with NaN coordinates): done = 1, the
+    MESHENV_MOVE_SMOOTH_RAISES = 4    /* the reference raises out of this move(): inside that smooth_pave
+                                         (MESHENV_SMOOTH_RAISES below) or, after a smooth_pave that accepted a NaN vertex
+                                         (MESHENV_SMOOTH_NONFINITE), in the find_next_state that follows it -- in the
+                                         second case not_valid_points has already been emptied, :416-422; done = 1, the
                                          caller resets */
 };
 /* No selectable reference vertex on a front of more than 4 vertices (every candidate is listed in not_valid_points):
@@ -241,17 +243,22 @@ int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, f
  *   sweeps_dev [n_envs] int32, nullable: sweeps of the interior relaxation; MESHENV_SMOOTH_SKIPPED for masked-out envs;
  *              MESHENV_SMOOTH_LOG_OVERFLOW (status bit MESHENV_ST_LOG_OVERFLOW: graph incomplete) and
  *              MESHENV_SMOOTH_DEGREE (a vertex with more than 16 neighbours) leave the env untouched;
- *              MESHENV_SMOOTH_RAISES: a vertex construction of the front smoother is undefined (math.sqrt of a negative
- *              number, division by zero: coincident front vertices) -- the vertices moved before that point stay
- *              moved, nothing else ran.  The reference raises there when the operands are Python floats; when a NumPy
- *              scalar is involved (coordinates of generated vertices are) a zero divisor only warns and it goes on
- *              with inf / NaN coordinates -- that continuation is not reproduced
+ *              MESHENV_SMOOTH_RAISES: the reference raises inside a vertex construction of the front smoother
+ *              (math.sqrt of a negative number; a zero divisor between Python operands, i.e. two coincident DOMAIN
+ *              vertices) -- the vertices moved before that point stay moved, nothing else ran.  A zero divisor with a
+ *              NumPy-scalar operand (the coordinates of generated vertices are np.float64) only warns in the reference
+ *              and yields nan: reproduced -- the nan position fails is_inside_boundary and the vertex stays where it
+ *              is -- except where the reference ACCEPTS the nan position (every test against the surrounding polygon
+ *              reads False for the original position too): MESHENV_SMOOTH_NONFINITE, the smoother stops at that vertex;
+ *              the reference goes on with a NaN vertex and raises in its next find_next_state (int(nan),
+ *              general/components.py:1249)
  *   diff_dev   [n_envs] float64, nullable: the last |sum - previous sum| (what the reference prints) */
 enum {
     MESHENV_SMOOTH_SKIPPED = -1, MESHENV_SMOOTH_LOG_OVERFLOW = -2, MESHENV_SMOOTH_DEGREE = -3,
     MESHENV_SMOOTH_NOT_FINISHED = -4, /* meshenv_smooth_final on a front of more than 5 vertices */
     MESHENV_SMOOTH_INDEX_ERROR = -5,  /* the reference raises IndexError here (empty common-neighbour list) */
-    MESHENV_SMOOTH_RAISES = -6
+    MESHENV_SMOOTH_RAISES = -6,
+    MESHENV_SMOOTH_NONFINITE = -7
 };
 int meshenv_smooth(MeshEnv *h, int which, const uint8_t *mask_dev, int iteration, int interior, int is_static,
                    int32_t *sweeps_dev, double *diff_dev, float *obs_dev);

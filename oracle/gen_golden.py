@@ -200,6 +200,10 @@ MOVE_TRACES = [
     ("move_rand903_s903", "RANDOM903", 903, 500, True),
     ("move_rand928_s928", "RANDOM928", 928, 500, True),
     ("move_rand906_s906", "RANDOM906", 906, 500, True),
+    # a self-touching generated polygon (doubled spike): coincident front vertices make the front smoother's vertex
+    # constructions divide by zero -- with a NumPy-scalar operand the reference warns and goes on (moves 993-995: `warned`),
+    # with Python operands it raises (move 996: code 4).  Inputs: the parity campaign's distribution.
+    ("move_rand7023_c1", "RANDOM7023", 1, 1200, True, "campaign"),
 ]
 
 
@@ -267,19 +271,21 @@ def main_front_smooth():
               f"{int(tr['call_raised'].sum()) if nc else 0} raised, {int(tr['call_obs_none'].sum()) if nc else 0} None")
 
 
-def main_move():
-    for name, dom, seed, T, reset_on_done in MOVE_TRACES:
+def main_move(only=None):
+    for name, dom, seed, T, reset_on_done, *kind in MOVE_TRACES:
+        if only and name not in only:
+            continue
         if isinstance(dom, str) and dom.startswith("RANDOM"):
             from reinforcementlearning4meshgeneration_amd.domains import random_domain
             pts = random_domain(int(dom[6:]))
         else:
             pts = H.domain_points(dom) if isinstance(dom, str) else dom
-        p, ty = H.move_inputs(seed, T)
+        p, ty = (H.campaign_move_inputs if kind == ["campaign"] else H.move_inputs)(seed, T)
         tr = H.record_move_trace(pts, p, ty, reset_on_done=reset_on_done)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **tr)
         print(f"{name}: {T} moves, {int(tr['valid'].sum())} valid, codes {np.bincount(tr['code'], minlength=4).tolist()}, "
               f"done {int(tr['done'].sum())}, complete {int(tr['complete'].sum())}, max not_valid {int(tr['n_not_valid'].max())}, "
-              f"through smooth_pave {int(tr['smoothed'].sum())}")
+              f"through smooth_pave {int(tr['smoothed'].sum())}, with NumPy zero-divisor warnings {int((tr['warned'] > 0).sum())}")
 
 
 def main():
@@ -293,7 +299,7 @@ def main():
         quality_fixture()
         return
     if "--move-only" in sys.argv:
-        main_move()
+        main_move(only=[a for a in sys.argv[1:] if a.startswith("move_")])
         return
     export_fixture()
     quality_fixture()

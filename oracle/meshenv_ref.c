@@ -897,6 +897,13 @@ int meshenv_ref_move(RefEnv *e, const double *point, double type, float *obs, ui
         if (none) { /* B:405-426: smooth_pave, then a fresh selection with an empty not_valid_points */
             int32_t sweeps = 0;
             int src = meshenv_ref_smooth_front(e);
+            if (src == -4) { /* a NaN vertex was accepted: B:416-422 run, then find_next_state raises (C:1257) */
+                e->last_count = e->n_nv;
+                if (e->n_nv > 0) { e->last_first = e->nv_id[0]; e->last_last = e->nv_id[e->n_nv - 1]; }
+                e->last_epoch = e->epoch;
+                e->n_nv = 0;
+                src = -3;
+            }
             if (src == -3) { *done_out = 1; *complete_out = 0; return MESHENV_REF_MOVE_SMOOTH_RAISES; } /* the caller resets */
             if (src == 0) src = meshenv_ref_smooth_interior(e, 400, &sweeps, NULL);
             if (src != 0) { /* log overflow: the graph cannot be rebuilt -- the episode ends here (not a reference path) */
@@ -1187,10 +1194,23 @@ int meshenv_ref_smooth_final(RefEnv *e, int iteration, double lr_1, double lr_2,
  * interior angle: <= 90 -> middle_vertex on the bisector for a target angle raised in steps of 5 until the new position
  * keeps every surrounding element on its side (is_inside_boundary over clockwise_vertices); (90, 180] -> side_vertex
  * next to a sharp (< 45) neighbour corner, else find_indention_vertex; (180, 270] -> find_indention_vertex; beyond ->
- * inner_vertex then find_indention_vertex.  Returns 0, -1 (log / degree overflow), -3 where a vertex construction is
- * undefined (math.sqrt of a negative number: ValueError in the reference; a zero divisor: ZeroDivisionError in the
- * reference if both operands are Python floats -- with a NumPy scalar involved it only warns and continues with inf / NaN
- * coordinates, which is NOT restated): the vertices moved before that stay moved. */
+ * inner_vertex then find_indention_vertex.  Returns 0, -1 (log / degree overflow), -3 where a vertex construction
+ * raises in the reference: the vertices moved before that stay moved.
+ *
+ * What raises (checked against the reference run side by side, oracle/check_move_vs_reference.py): math.sqrt of a
+ * negative number or of -inf (ValueError; math.sqrt(nan) returns nan) -- and a zero divisor ONLY when both operands are
+ * Python numbers.  Coordinates of domain vertices are Python floats / ints, coordinates of generated vertices are
+ * np.float64 (B:123 rounds a NumPy array element; the same provenance rule as round4_by above: id >= n0 <=> NumPy), and
+ * `python_float / np.float64(0.0)` is NumPy's division: a RuntimeWarning and inf / nan, execution continues.  The zero
+ * divisors of this code are coordinate differences of two coincident vertices (A == 0 and B == 0 at once), where the
+ * numerator W = dist * |p - q| * cos(..) is 0 as well, so the quotient is nan, every comparison on the candidate
+ * position is False, is_inside_boundary rejects it for every trial and the vertex stays where it is (M:1048-1066) --
+ * unless every entry of the surrounding polygon already reads >= pi for the original position, in which case the
+ * reference assigns nan coordinates and goes on; that continuation (a NaN vertex in the front, int(nan) raising in the
+ * next get_radius_points: ValueError, C:1257) is not restated step by step: a non-finite accepted position ends the
+ * front smoother with -4, which move() turns into what the reference does next -- B:416-422 (the not_valid_points
+ * bookkeeping) and then the raise out of find_next_state: the same return as -3, with the list already cleared
+ * (tests/golden/move_rand7023_c1.npz, move 996). */
 typedef struct {
     RefEnv *e;
     Graph g;
@@ -1199,13 +1219,14 @@ typedef struct {
 
 static double py_sqrt(Front *f, double v)
 {
-    if (v < 0) { f->raised = 1; return 0.0; } /* ValueError: math domain error */
+    if (v < 0) { f->raised = 1; return 0.0; } /* ValueError: math domain error (nan passes: math.sqrt(nan) = nan) */
     return sqrt(v);
 }
 
-static double py_div(Front *f, double a, double b)
+/* a / b where the divisor's type follows its operands: is_np != 0 -> NumPy scalar division (IEEE: inf / nan, a warning) */
+static double py_div(Front *f, double a, double b, int is_np)
 {
-    if (b == 0) { f->raised = 1; return 0.0; } /* ZeroDivisionError */
+    if (b == 0 && !is_np) { f->raised = 1; return 0.0; } /* ZeroDivisionError */
     return a / b;
 }
 
@@ -1213,10 +1234,10 @@ static double deg2rad(double a) { return a * (PI / 180.0); } /* math.radians */
 static double rad2deg(double a) { return a * (180.0 / PI); } /* math.degrees */
 
 /* the two intersections of the circle |p - (a, b)| = dist with the line A x + B y = W + A a + B b, M:841-858 / 889-904 */
-static void circle_line(Front *f, double a, double b, double A, double B, double W, double dist, P2 *v1, P2 *v2)
+static void circle_line(Front *f, double a, double b, double A, double B, double W, double dist, int np_A, P2 *v1, P2 *v2)
 {
     if (B == 0) {
-        double wa = py_div(f, W, A);
+        double wa = py_div(f, W, A, np_A); /* W is a Python float (math.sqrt / math.cos products) */
         double r = py_sqrt(f, SQ(dist) - SQ(wa));
         v1->x = wa + a; v2->x = wa + a;
         v1->y = b + r; v2->y = b - r;
@@ -1265,20 +1286,20 @@ static P2 middle_vertex(Front *f, P2 vertex, P2 left, P2 right, double target_an
 }
 
 /* M:834-863 */
-static P2 side_vertex(Front *f, P2 vertex, P2 next_v, P2 nn_v, double angle, double d)
+static P2 side_vertex(Front *f, P2 vertex, P2 next_v, P2 nn_v, double angle, double d, int np_A)
 {
     double W = d * dist(next_v, nn_v) * cos(deg2rad(angle));
     P2 v1, v2;
-    circle_line(f, next_v.x, next_v.y, nn_v.x - next_v.x, nn_v.y - next_v.y, W, d, &v1, &v2);
+    circle_line(f, next_v.x, next_v.y, nn_v.x - next_v.x, nn_v.y - next_v.y, W, d, np_A, &v1, &v2);
     return dist(v1, vertex) < dist(v2, vertex) ? v1 : v2;
 }
 
 /* M:882-909 */
-static P2 indention_vertex(Front *f, P2 vertex, P2 left, P2 right, double angle, double d)
+static P2 indention_vertex(Front *f, P2 vertex, P2 left, P2 right, double angle, double d, int np_A)
 {
     double W = d * dist(vertex, left) * cos(deg2rad(angle));
     P2 v1, v2;
-    circle_line(f, vertex.x, vertex.y, left.x - vertex.x, left.y - vertex.y, W, d, &v1, &v2);
+    circle_line(f, vertex.x, vertex.y, left.x - vertex.x, left.y - vertex.y, W, d, np_A, &v1, &v2);
     return cw(v1, left, right) < cw(v2, left, right) ? v1 : v2;
 }
 
@@ -1333,7 +1354,7 @@ static P2 find_side_vertex(Front *f, int v, int _next, int next, int nn, double 
     const double d = (dist(pv, e->vtab[_next]) + dist(pv, e->vtab[next]) + dist(e->vtab[next], e->vtab[nn])) / 3;
     double target = 45;
     for (;;) {
-        P2 nv = side_vertex(f, pv, e->vtab[next], e->vtab[nn], target, d);
+        P2 nv = side_vertex(f, pv, e->vtab[next], e->vtab[nn], target, d, next >= e->n0 || nn >= e->n0);
         if (f->raised) return pv;
         if (target <= v_angle) return pv;
         int cb[2 * MESHENV_REF_MAX_DEG];
@@ -1359,13 +1380,16 @@ static P2 find_indention_vertex(Front *f, int index, double v_angle)
         if (w == v || w == r2 || w == right || w == left || w == l2) continue;
         if (dist(pv, e->vtab[w]) <= d) near = 1;
     }
-    /* find_closest_segments, M:1103-1112: a front segment (not at the vertex) whose foot point lies inside it, within d */
-    for (int i = 0; i < n && !near; i++) {
+    /* find_closest_segments, M:1103-1112: a front segment (not at the vertex) whose foot point lies inside it, within d.
+     * Both loops of the reference run to the end whatever they find, so a zero-length segment between two domain vertices
+     * raises (C:647, Python operands) even when a near vertex was already seen; with a generated endpoint the quotient is
+     * 0 / np.float64(0) = nan and the segment is simply not "inner". */
+    for (int i = 0; i < n; i++) {
         int p1 = e->rid[RI(i - 1, n)], p2 = e->rid[i];
         if (p1 == v || p2 == v) continue;
         const P2 a = e->vtab[p1], b = e->vtab[p2];
         double A = b.x - a.x, B = b.y - a.y;
-        double s = py_div(f, A * pv.x + B * pv.y - B * a.y - A * a.x, SQ(A) + SQ(B));
+        double s = py_div(f, A * pv.x + B * pv.y - B * a.y - A * a.x, SQ(A) + SQ(B), p1 >= e->n0 || p2 >= e->n0);
         if (f->raised) return pv;
         P2 t = {a.x + s * A, a.y + s * B};
         if (0 <= s && s <= 1 && dist(pv, t) <= d) near = 1;
@@ -1373,7 +1397,7 @@ static P2 find_indention_vertex(Front *f, int index, double v_angle)
     if (!near) return pv;
     int times = 4;
     for (;;) {
-        P2 nv = indention_vertex(f, pv, e->vtab[left], e->vtab[right], (360 - v_angle) / 2, d / times);
+        P2 nv = indention_vertex(f, pv, e->vtab[left], e->vtab[right], (360 - v_angle) / 2, d / times, v >= e->n0 || left >= e->n0);
         if (f->raised) return pv;
         if (times >= 10) return pv;
         int cb[2 * MESHENV_REF_MAX_DEG];
@@ -1417,8 +1441,8 @@ int meshenv_ref_front_construction(int which, const double *in, double *out_xy)
     f.e = NULL; f.g.adj = NULL; f.g.deg = NULL; f.raised = 0;
     P2 v = {in[0], in[1]}, a = {in[2], in[3]}, b = {in[4], in[5]}, r;
     if (which == 0) r = middle_vertex(&f, v, a, b, in[6]);
-    else if (which == 1) r = side_vertex(&f, v, a, b, in[6], in[7]);
-    else if (which == 2) r = indention_vertex(&f, v, a, b, in[6], in[7]);
+    else if (which == 1) r = side_vertex(&f, v, a, b, in[6], in[7], 0);
+    else if (which == 2) r = indention_vertex(&f, v, a, b, in[6], in[7], 0);
     else r = estimate_4th_vertex(v, a, b, in[6], in[7] >= 0, in[7]); /* 3: Mesh.estimate_4th_vertex(origin, left, right, factor, suggest_dist | None) */
     out_xy[0] = r.x; out_xy[1] = r.y;
     return f.raised;
@@ -1464,20 +1488,23 @@ int meshenv_ref_smooth_front(RefEnv *e)
             P2 m = {(l.x + r.x) / 2, (l.y + r.y) / 2};
             double d = dist(m, r) * tan(deg2rad(45));
             double A = pv.x - m.x, B = pv.y - m.y;
-            double q = py_div(&f, SQ(d), SQ(A) + SQ(B));
+            double q = py_div(&f, SQ(d), SQ(A) + SQ(B), 1); /* A = vertex.x - m.x: the vertex is a generated one (NumPy) */
             if (f.raised) break;
-            double sc = sqrt(q);
+            double sc = py_sqrt(&f, q);
+            if (f.raised) break;
+            if (!isfinite(m.x + sc * A) || !isfinite(m.y + sc * B)) { f.raised = 2; break; } /* see the header */
             e->vtab[v].x = m.x + sc * A;
             e->vtab[v].y = m.y + sc * B;
             e->ring[i] = e->vtab[v];
             nv = find_indention_vertex(&f, i, v_angle);
         }
         if (f.raised) break;
+        if (!isfinite(nv.x) || !isfinite(nv.y)) { f.raised = 2; break; } /* see the header */
         e->vtab[v] = nv;
         e->ring[i] = nv;
     }
     free(f.g.adj); free(f.g.deg);
-    return f.raised ? -3 : 0;
+    return f.raised == 2 ? -4 : (f.raised ? -3 : 0);
 }
 
 /* smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=..., interior=False), M:790-795, followed by the
@@ -1487,6 +1514,7 @@ int meshenv_ref_smooth_front(RefEnv *e)
 int meshenv_ref_smooth_pave_full(RefEnv *e, int iteration, int is_static, float *obs, int32_t *sweeps_out)
 {
     int rc = meshenv_ref_smooth_front(e);
+    if (rc == -4) rc = -3; /* the reference raises either way: inside smooth_pave, or in the find_next_state after it */
     if (rc != 0) return rc;
     rc = meshenv_ref_smooth_interior(e, iteration, sweeps_out, NULL);
     if (rc != 0) return rc;

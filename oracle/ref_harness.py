@@ -221,6 +221,17 @@ def move_inputs(seed: int, T: int):
     return pts.astype(np.float64), types.astype(np.float64)
 
 
+def campaign_move_inputs(seed: int, T: int):
+    """The parity campaign's move() inputs (tools/parity_campaign.py, oracle/check_move_vs_reference.py): radius fraction
+    U(0.05, 0.45), angle U(0.2, 1.5), type U(0, 1), drawn move by move."""
+    rng = np.random.default_rng(seed)
+    pts, types = np.zeros((T, 2)), np.zeros(T)
+    for t in range(T):
+        pts[t] = (float(rng.uniform(0.05, 0.45)), float(rng.uniform(0.2, 1.5)))
+        types[t] = float(rng.uniform(0, 1))
+    return pts, types
+
+
 def record_move_trace(points, pts: np.ndarray, types: np.ndarray, static_reset: bool = True,
                       reset_on_done: bool = True) -> dict:
     """Drive the reference's move() with Python floats and record what parity needs.  A call the reference cannot answer
@@ -250,22 +261,28 @@ def record_move_trace(points, pts: np.ndarray, types: np.ndarray, static_reset: 
         complete=np.zeros(T, np.uint8), ring_len=np.zeros(T, np.int32), ring_ids=np.full((T, n0), -1, np.int32),
         ref_id=np.full(T, -1, np.int32), n_elem=np.zeros(T, np.int32), n_not_valid=np.zeros(T, np.int32),
         new_xy=np.full((T, 2), np.nan, np.float64), valid=np.zeros(T, np.uint8), was_reset=np.zeros(T, np.uint8),
-        smoothed=np.zeros(T, np.uint8),
+        smoothed=np.zeros(T, np.uint8), warned=np.zeros(T, np.uint8),
     )
+    import warnings
     for t in range(T):
         nverts_before = len(env.boundary.vertices)
         nelem_before = len(env.generated_meshes)
         smoothed_flag[0] = 0
-        try:
-            obs, rew, done, info = env.move([float(pts[t, 0]), float(pts[t, 1])], float(types[t]))
-            assert rew == 0
-            code = 1 if obs is None else 0
-            comp = info["is_complete"]
-        except UnboundLocalError:
-            obs, done, comp, code = None, False, False, 2
-        except (ValueError, ZeroDivisionError):
-            assert smoothed_flag[0]
-            obs, done, comp, code = None, True, False, 4
+        # `warned`: NumPy RuntimeWarnings inside the call = a zero divisor with a NumPy-scalar operand in one of the front
+        # smoother's vertex constructions (the reference goes on with nan; with Python operands it raises: code 4)
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            try:
+                obs, rew, done, info = env.move([float(pts[t, 0]), float(pts[t, 1])], float(types[t]))
+                assert rew == 0
+                code = 1 if obs is None else 0
+                comp = info["is_complete"]
+            except UnboundLocalError:
+                obs, done, comp, code = None, False, False, 2
+            except (ValueError, ZeroDivisionError):
+                assert smoothed_flag[0]
+                obs, done, comp, code = None, True, False, 4
+        out["warned"][t] = min(255, len(wlist))
         out["code"][t] = code
         out["smoothed"][t] = smoothed_flag[0]
         if obs is not None:

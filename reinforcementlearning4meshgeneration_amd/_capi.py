@@ -14,6 +14,7 @@ ST_NO_REFERENCE = 1
 ST_LOG_OVERFLOW = 2
 MOVE_OK, MOVE_NONE, MOVE_RAISES, MOVE_NEEDS_SMOOTHING, MOVE_SMOOTH_RAISES = 0, 1, 2, 3, 4
 SMOOTH_SKIPPED, SMOOTH_LOG_OVERFLOW, SMOOTH_DEGREE, SMOOTH_NOT_FINISHED, SMOOTH_INDEX_ERROR, SMOOTH_RAISES = -1, -2, -3, -4, -5, -6
+SMOOTH_NONFINITE = -7
 
 
 class MeshEnvParams(C.Structure):

@@ -112,6 +112,9 @@ class BoudaryEnv:  # the reference's spelling
         n = int(sweeps.cpu()[0])
         if n == _capi.SMOOTH_RAISES:
             raise ValueError("math domain error / division by zero inside smooth_current_boundary_3, as in the reference")
+        if n == _capi.SMOOTH_NONFINITE:
+            # the reference accepts the nan position here and raises in the find_next_state its callers run next
+            raise ValueError("cannot convert float NaN to integer (a NaN vertex accepted by smooth_current_boundary_3)")
         if n < 0:
             raise RuntimeError(f"smooth_pave(): not applicable to this episode (code {n}: see _capi.SMOOTH_*)")
         if not interior:

@@ -48,6 +48,8 @@ struct MeshEnv {
     std::vector<hipEvent_t> ev;  // 2 * MESHENV_TIMING_POOL events, created on first use
     int32_t *smooth_sweeps = nullptr;  // [E], allocated by the first meshenv_smooth: what the smoother did per env
     int32_t *front_code = nullptr;     // [E] outcome of the front smoother (gates the interior pass of the same call)
+    double *front_tab = nullptr;       // [kFtTotal] the front smoother's tan / cos values from the host's libm
+    bool smooth_ready = false, move_ready = false;   // set only after every allocation / attribute call succeeded
     Reselect *pend = nullptr;          // [E] selection parked by the candidate rebuild (csrc/meshenv_smooth.h)
     float *pend_obs = nullptr;         // [E][18]
     bool reselect_pending = false;     // a rebuild ran since the last step kernel
@@ -514,24 +516,59 @@ int meshenv_reset_static(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev, in
 
 int meshenv_reset(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev) { return meshenv_reset_static(h, mask_dev, obs_dev, 0); }
 
+// The front smoother's tan / cos values (csrc/meshenv_smooth.h, "kFt..."): every argument derives from a clockwise angle
+// quantised to 1e-4 rad or from a literal, so the host evaluates them all once with ITS libm -- the one the reference's
+// math.tan / math.cos call -- in exactly the reference's expression order (math.radians(x) = x * (pi / 180),
+// math.degrees(x) = x * (180 / pi); general/mesh.py:809, 839, 872, 886, 953-972, 1048).
+static void fill_front_tables(std::vector<double> &t)
+{
+    // volatile: the calls below must reach the libm of the running process, not be folded by the compiler
+    volatile double pi_v = 3.141592653589793;
+    const double pi = pi_v, to_rad = pi / 180.0, to_deg = 180.0 / pi;
+    t.assign(kFtTotal, 0.0);
+    for (int q = 0; q < kFtQ; q++) {
+        const double v_angle = ((double)q / 1e4) * to_deg;
+        t[kFtCosInd + q] = std::cos(((360 - v_angle) / 2) * to_rad);
+    }
+    t[kFtTan45] = std::tan(45.0 * to_rad);
+    for (int k = 0; k < 10; k++) t[kFtCosSide + k] = std::cos((45.0 - 5.0 * k) * to_rad);
+    for (int row = 0; row <= kFtMidQ1 - kFtMidQ0 + 1; row++) {
+        double target = row == 0 ? 45.0 : ((double)(kFtMidQ0 + row - 1) / 1e4) * to_deg;
+        for (int k = 0; k < kFtMidSteps; k++) {
+            t[kFtTanMid + row * kFtMidSteps + k] = std::tan((target / 2) * to_rad);
+            target += 5;
+        }
+    }
+}
+
 // buffers and kernel attributes of the smoothing entry points, on first use
 static int ensure_smooth_state(MeshEnv *h)
 {
-    if (h->smooth_sweeps) return MESHENV_OK;
-    int rc = dev_alloc(h, &h->smooth_sweeps, (size_t)h->n_envs);
+    if (h->smooth_ready) return MESHENV_OK;
+    int rc = MESHENV_OK;
+    if (!h->smooth_sweeps) rc = dev_alloc(h, &h->smooth_sweeps, (size_t)h->n_envs);
     if (rc != MESHENV_OK) return rc;
-    rc = dev_alloc(h, &h->front_code, (size_t)h->n_envs);
+    if (!h->front_code) rc = dev_alloc(h, &h->front_code, (size_t)h->n_envs);
     if (rc != MESHENV_OK) return rc;
     HIP_TRY(h, hipFuncSetAttribute((const void *)k_smooth_interior, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute((const void *)k_smooth_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(h, hipFuncSetAttribute((const void *)k_rebuild_candidates<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    rc = dev_alloc(h, &h->pend, (size_t)h->n_envs);
+    if (!h->pend) rc = dev_alloc(h, &h->pend, (size_t)h->n_envs);
     if (rc != MESHENV_OK) return rc;
-    rc = dev_alloc(h, &h->pend_obs, (size_t)h->n_envs * kObsDim);
+    if (!h->pend_obs) rc = dev_alloc(h, &h->pend_obs, (size_t)h->n_envs * kObsDim);
     if (rc != MESHENV_OK) return rc;
     HIP_TRY(h, hipMemsetAsync(h->pend, 0xff, sizeof(Reselect) * (size_t)h->n_envs, h->stream));   // n_elem = -1: nothing parked
+    if (!h->front_tab) rc = dev_alloc(h, &h->front_tab, (size_t)kFtTotal);
+    if (rc != MESHENV_OK) return rc;
+    {
+        std::vector<double> tab;
+        fill_front_tables(tab);
+        // synchronous copy from pageable memory: the vector may go out of scope right after
+        HIP_TRY(h, hipMemcpy(h->front_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+    }
+    h->smooth_ready = true;   // only now: a failure above leaves the state "not ready" and the next call tries again
     return MESHENV_OK;
 }
 
@@ -543,7 +580,7 @@ static int launch_full_smoothing(MeshEnv *h, const uint8_t *mask_dev, int iterat
     const int log_cap = h->S.prm.log_cap;
     const dim3 grid(h->n_envs), block(64);
     hipLaunchKernelGGL(k_smooth_front, grid, block, smooth_front_lds_bytes(h->cap, log_cap), h->stream, h->S, h->cap, mask_dev,
-                       h->front_code);
+                       h->front_code, (const double *)h->front_tab);
     HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(k_smooth_interior, grid, block, smooth_lds_bytes(h->cap, log_cap), h->stream, h->S, h->cap, 0, mask_dev,
                        h->front_code, iteration, sw, diff_dev);
@@ -568,22 +605,24 @@ static bool smoothing_fits(const MeshEnv *h, bool with_front)
 
 static int ensure_move_state(MeshEnv *h)
 {
-    if (h->nv_xy) return MESHENV_OK;
+    if (h->move_ready) return MESHENV_OK;
     const size_t total = (size_t)h->n_envs * (size_t)h->cap;
-    int rc = dev_alloc(h, &h->nv_xy, total);
+    int rc = MESHENV_OK;
+    if (!h->nv_xy) rc = dev_alloc(h, &h->nv_xy, total);
     if (rc != MESHENV_OK) return rc;
-    rc = dev_alloc(h, &h->nv_count, (size_t)h->n_envs);
+    if (!h->nv_count) rc = dev_alloc(h, &h->nv_count, (size_t)h->n_envs);
     if (rc != MESHENV_OK) return rc;
     HIP_TRY(h, hipMemsetAsync(h->nv_count, 0, sizeof(int32_t) * (size_t)h->n_envs, h->stream));
-    rc = dev_alloc(h, &h->nv_gid, total);
+    if (!h->nv_gid) rc = dev_alloc(h, &h->nv_gid, total);
     if (rc != MESHENV_OK) return rc;
-    rc = dev_alloc(h, &h->nv_meta, (size_t)h->n_envs * kNvMeta);
+    if (!h->nv_meta) rc = dev_alloc(h, &h->nv_meta, (size_t)h->n_envs * kNvMeta);
     if (rc != MESHENV_OK) return rc;
     HIP_TRY(h, hipMemsetAsync(h->nv_meta, 0, sizeof(int32_t) * (size_t)h->n_envs * kNvMeta, h->stream));
-    rc = dev_alloc(h, &h->move_mask, (size_t)h->n_envs);
+    if (!h->move_mask) rc = dev_alloc(h, &h->move_mask, (size_t)h->n_envs);
     if (rc != MESHENV_OK) return rc;
     if (move_lds_bytes(h->cap) > 64 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)k_move, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    h->move_ready = true;   // only now (see ensure_smooth_state)
     return MESHENV_OK;
 }
 
@@ -685,7 +724,7 @@ int meshenv_get_not_valid(MeshEnv *h, int env, double *xy_host, int cap_points, 
         return MESHENV_E_RANGE;
     }
     *count = 0;
-    if (!h->nv_xy) return MESHENV_OK;  // move() never called: the list is empty
+    if (!h->move_ready) return MESHENV_OK;  // move() never called: the list is empty
     MESHENV_ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     int32_t n = 0;
@@ -707,7 +746,7 @@ int meshenv_get_not_valid_ids(MeshEnv *h, int env, int32_t *ids_host, int cap_id
     }
     *count = 0;
     if (last_host) last_host[0] = last_host[1] = last_host[2] = last_host[3] = 0;
-    if (!h->nv_xy) return MESHENV_OK;  // move() never called
+    if (!h->move_ready) return MESHENV_OK;  // move() never called
     MESHENV_ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     int32_t n = 0, meta[kNvMeta];
@@ -1029,16 +1068,18 @@ __global__ void k_selftest(int what, int n, const double *in, double *out)
         out[i] = ne ? 1.0 : ((f == e && signbit(f) == signbit(e)) ? 0.0 : 2.0);
     } else if (what == 9 || what == 10) {
         // the front smoother's vertex constructions (csrc/meshenv_smooth.h): 9 doubles = which (0 middle_vertex, 1 side_vertex,
-        // 2 indention_vertex), vertex, p1, p2, angle, dist; what 9 -> x, 10 -> y; NaN where the construction is undefined
+        // 2 indention_vertex), vertex, p1, p2, angle, dist; what 9 -> x, 10 -> y; NaN where the construction is undefined.
+        // As in the product path the tan / cos of the angle come from the host's libm: meshenv_selftest replaces the angle
+        // by math.tan(math.radians(angle / 2)) (which 0) or math.cos(math.radians(angle)) (which 1, 2) before the upload.
         const double *q = in + 9 * (size_t)i;
         FrontState f;
-        f.coord = nullptr; f.adj = nullptr; f.deg = nullptr; f.ringu = nullptr; f.n = 0; f.raised = false;
+        f.coord = nullptr; f.adj = nullptr; f.deg = nullptr; f.ringu = nullptr; f.n = 0; f.n0 = 0; f.raised = 0; f.tab = nullptr;
         const P2 v = mkp(q[1], q[2]), a = mkp(q[3], q[4]), b = mkp(q[5], q[6]);
         const int which = (int)q[0];
         P2 r;
         if (which == 0) r = middle_vertex(v, a, b, q[7]);
-        else if (which == 1) r = side_vertex(f, v, a, b, q[7], q[8]);
-        else if (which == 2) r = indention_vertex(f, v, a, b, q[7], q[8]);
+        else if (which == 1) r = side_vertex(f, v, a, b, q[7], q[8], false);
+        else if (which == 2) r = indention_vertex(f, v, a, b, q[7], q[8], false);
         else {  // 3: Mesh.estimate_4th_vertex(origin, left, right, factor, suggest_dist or < 0 for None)
             const double2 e = estimate_4th_vertex(make_double2(v.x, v.y), make_double2(a.x, a.y), make_double2(b.x, b.y), q[7], q[8] >= 0, q[8]);
             r = mkp(e.x, e.y);
@@ -1056,6 +1097,19 @@ int meshenv_selftest(int device, int what, int n, int in_per_item, const double 
     if (hipMalloc(&din, sizeof(double) * (size_t)n * in_per_item) != hipSuccess) return MESHENV_E_HIP;
     if (hipMalloc(&dout, sizeof(double) * (size_t)n) != hipSuccess) { (void)hipFree(din); return MESHENV_E_HIP; }
     int rc = MESHENV_OK;
+    std::vector<double> staged;
+    if ((what == 9 || what == 10) && in_per_item == 9) {   // the constructions take the host libm's tan / cos (see k_selftest)
+        staged.assign(in_host, in_host + (size_t)n * 9);
+        volatile double pi_v = 3.141592653589793;
+        const double to_rad = pi_v / 180.0;
+        for (int i = 0; i < n; i++) {
+            double *q = staged.data() + 9 * (size_t)i;
+            const int which = (int)q[0];
+            if (which == 0) q[7] = std::tan((q[7] / 2) * to_rad);
+            else if (which == 1 || which == 2) q[7] = std::cos(q[7] * to_rad);
+        }
+        in_host = staged.data();
+    }
     if (hipMemcpy(din, in_host, sizeof(double) * (size_t)n * in_per_item, hipMemcpyHostToDevice) != hipSuccess) rc = MESHENV_E_HIP;
     if (rc == MESHENV_OK) {
         hipLaunchKernelGGL(k_selftest, dim3((n + 63) / 64), dim3(64), 0, nullptr, what, n, din, dout);

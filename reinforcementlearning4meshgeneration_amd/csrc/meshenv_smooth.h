@@ -30,7 +30,8 @@ namespace meshenv {
 
 constexpr int kSmoothMaxDeg = 16;   // neighbours per generated vertex (a quad-mesh vertex has 3-6; more sets code -3)
 
-enum { kSmoothSkipped = -1, kSmoothLogOverflow = -2, kSmoothDegree = -3, kSmoothNotFinished = -4, kSmoothIndexError = -5, kSmoothRaises = -6 };
+enum { kSmoothSkipped = -1, kSmoothLogOverflow = -2, kSmoothDegree = -3, kSmoothNotFinished = -4, kSmoothIndexError = -5, kSmoothRaises = -6,
+       kSmoothNonFinite = -7 };
 
 // LDS: coord[ring_cap + log_cap] double2 | xy_sum[log_cap] double | adj[log_cap][16] uint16 | lvl[log_cap] uint16 |
 //      deg[log_cap] uint8 | front[log_cap] uint8
@@ -533,13 +534,30 @@ k_smooth_final(DevState S, int ring_cap, int which, const uint8_t *__restrict__ 
 // atan2-heavy inner loops -- one lane per entry of the surrounding polygon in is_inside_boundary, one lane per front
 // vertex / segment in find_indention_vertex's proximity tests.  Graph and coordinates as in k_smooth_final.
 
+// Every tan / cos of the front smoother has an argument derived from a QUANTISED angle (to_find_clockwise_angle rounds to
+// 1e-4 rad: 62 833 possible values) or from a literal, so the values the reference's libm returns are a finite table.
+// The host fills it with its own libm at the first smoothing call (fill_front_tables, csrc/meshenv_hip.hip) -- the libm
+// the reference's math.tan / math.cos call in the same process -- and the kernel reads it: bit-identical to the reference
+// by construction, where ocml's tan / cos differ from glibc's in the last bit of ~10 % of the arguments.
+//   [kFtCosInd + q]            cos(radians((360 - degrees(q e-4)) / 2))       indention_vertex, M:1048 / 886
+//   [kFtTan45]                 tan(radians(45))                               inner_vertex, M:872
+//   [kFtCosSide + k]           cos(radians(45 - 5 k)), k = 0..9               side_vertex via find_side_vertex, M:919-934
+//   [kFtTanMid + 19 row + k]   tan(radians(t_k / 2)), t_0 = 45 (row 0) or degrees(q e-4) >= 45 (row q - kFtMidQ0 + 1),
+//                              t_{k+1} = t_k + 5                              middle_vertex, M:809 with M:953-972
+constexpr int kFtQ = 62833;
+constexpr int kFtCosInd = 0, kFtTan45 = kFtQ, kFtCosSide = kFtQ + 1, kFtTanMid = kFtQ + 16;
+constexpr int kFtMidQ0 = 7853, kFtMidQ1 = 15709, kFtMidSteps = 19;
+constexpr int kFtTotal = kFtTanMid + (kFtMidQ1 - kFtMidQ0 + 2) * kFtMidSteps;
+
 struct FrontState {
     double2 *coord;
     const unsigned short *adj;
     const unsigned char *deg;
     const unsigned short *ringu;
-    int n;
-    bool raised;   // the reference raises here (math.sqrt of a negative number, division by zero)
+    const double *tab;   // the table above
+    int n, n0;
+    int raised;    // 1: the reference raises here (math.sqrt of a negative number, a zero divisor between Python operands);
+                   // 2: a construction with a NumPy zero divisor produced nan and the reference ACCEPTED it (see k_smooth_front)
 };
 
 __device__ __forceinline__ P2 ldc(const FrontState &f, int v)
@@ -550,25 +568,31 @@ __device__ __forceinline__ P2 ldc(const FrontState &f, int v)
 
 __device__ __forceinline__ double py_sqrt(FrontState &f, double v)
 {
-    if (v < 0) { f.raised = true; return 0.0; }
+    if (v < 0) { f.raised = 1; return 0.0; }   // ValueError (also -inf); math.sqrt(nan) is nan
     return sqrt(v);
 }
 
-__device__ __forceinline__ double py_div(FrontState &f, double a, double b)
+// a / b as the reference evaluates it: ZeroDivisionError when both operands are Python numbers, NumPy's IEEE quotient
+// (inf / nan and a warning) when one of them is an np.float64 -- the coordinates of generated vertices are (B:123 rounds
+// an array element), those of domain vertices are not: is_np = "a generated vertex's coordinate went into the divisor".
+__device__ __forceinline__ double py_div(FrontState &f, double a, double b, bool is_np)
 {
-    if (b == 0) { f.raised = true; return 0.0; }
+    if (b == 0 && !is_np) { f.raised = 1; return 0.0; }
     return a / b;
 }
 
 __device__ __forceinline__ double deg2rad(double a) { return a * (kPi / 180.0); }   // math.radians
 __device__ __forceinline__ double rad2deg(double a) { return a * (180.0 / kPi); }   // math.degrees
 
+// quantum index of a clockwise angle (the angle is the double nearest to q e-4)
+__device__ __forceinline__ int angle_q(double a) { return (int)rint(a * 1e4); }
+
 // the two intersections of the circle |p - (a, b)| = dist with the line A x + B y = W + A a + B b, M:841-858 / 889-904
 __device__ __forceinline__ void circle_line(FrontState &f, double a, double b, double A, double B, double W, double dist_,
-                                            P2 &v1, P2 &v2)
+                                            bool np_A, P2 &v1, P2 &v2)
 {
     if (B == 0) {
-        const double wa = py_div(f, W, A);
+        const double wa = py_div(f, W, A, np_A);   // W is a Python float (products of math.sqrt / math.cos results)
         const double r = py_sqrt(f, dist_ * dist_ - wa * wa);
         v1 = mkp(wa + a, b + r);
         v2 = mkp(wa + a, b - r);
@@ -591,12 +615,12 @@ __device__ __forceinline__ void circle_line(FrontState &f, double a, double b, d
     }
 }
 
-// M:805-832
-__device__ __forceinline__ P2 middle_vertex(P2 vertex, P2 left, P2 right, double target_angle)
+// M:805-832; tan_half = math.tan(math.radians(target_angle / 2)) from the table
+__device__ __forceinline__ P2 middle_vertex(P2 vertex, P2 left, P2 right, double tan_half)
 {
     const P2 m = mkp((left.x + right.x) / 2, (left.y + right.y) / 2);
     const double A = right.x - left.x, B = right.y - left.y;
-    const double D = dist(left, m) / tan(deg2rad(target_angle / 2));
+    const double D = dist(left, m) / tan_half;
     P2 v1, v2;
     if (B == 0) {
         v1 = mkp(m.x, m.y + D);
@@ -619,21 +643,21 @@ __device__ __forceinline__ P2 middle_vertex(P2 vertex, P2 left, P2 right, double
     return dist(v1, vertex) < dist(v2, vertex) ? v1 : v2;
 }
 
-// M:834-863
-__device__ __forceinline__ P2 side_vertex(FrontState &f, P2 vertex, P2 next_v, P2 nn_v, double angle, double d)
+// M:834-863; cos_a = math.cos(math.radians(angle)) from the table
+__device__ __forceinline__ P2 side_vertex(FrontState &f, P2 vertex, P2 next_v, P2 nn_v, double cos_a, double d, bool np_A)
 {
-    const double W = d * dist(next_v, nn_v) * cos(deg2rad(angle));
+    const double W = d * dist(next_v, nn_v) * cos_a;
     P2 v1, v2;
-    circle_line(f, next_v.x, next_v.y, nn_v.x - next_v.x, nn_v.y - next_v.y, W, d, v1, v2);
+    circle_line(f, next_v.x, next_v.y, nn_v.x - next_v.x, nn_v.y - next_v.y, W, d, np_A, v1, v2);
     return dist(v1, vertex) < dist(v2, vertex) ? v1 : v2;
 }
 
 // M:882-909
-__device__ __forceinline__ P2 indention_vertex(FrontState &f, P2 vertex, P2 left, P2 right, double angle, double d)
+__device__ __forceinline__ P2 indention_vertex(FrontState &f, P2 vertex, P2 left, P2 right, double cos_a, double d, bool np_A)
 {
-    const double W = d * dist(vertex, left) * cos(deg2rad(angle));
+    const double W = d * dist(vertex, left) * cos_a;
     P2 v1, v2;
-    circle_line(f, vertex.x, vertex.y, left.x - vertex.x, left.y - vertex.y, W, d, v1, v2);
+    circle_line(f, vertex.x, vertex.y, left.x - vertex.x, left.y - vertex.y, W, d, np_A, v1, v2);
     if (f.raised) return vertex;
     return cw(v1, left, right) < cw(v2, left, right) ? v1 : v2;
 }
@@ -721,9 +745,10 @@ __device__ __forceinline__ P2 find_side_vertex(FrontState &f, int v, int _next, 
 {
     const P2 pv = ldc(f, v), pn = ldc(f, next), pnn = ldc(f, nn);
     const double d = (dist(pv, ldc(f, _next)) + dist(pv, pn) + dist(pn, pnn)) / 3;
+    const bool np_A = next >= f.n0 || nn >= f.n0;
     double target = 45;
-    for (int guard = 0; guard < 16; guard++) {
-        const P2 nv = side_vertex(f, pv, pn, pnn, target, d);
+    for (int k = 0; k < 10; k++) {   // target = 45 - 5 k reaches 0 <= v_angle at k = 9 at the latest
+        const P2 nv = side_vertex(f, pv, pn, pnn, f.tab[kFtCosSide + k], d, np_A);
         if (f.raised) return pv;
         if (target <= v_angle) return pv;
         const int nb = clockwise_vertices(f, v, cb);
@@ -733,8 +758,8 @@ __device__ __forceinline__ P2 find_side_vertex(FrontState &f, int v, int _next, 
     return pv;
 }
 
-// M:1030-1067 with indention_vertex M:882-909; index = ring slot of the vertex
-__device__ __forceinline__ P2 find_indention_vertex(FrontState &f, int index, double v_angle, unsigned short *cb)
+// M:1030-1067 with indention_vertex M:882-909; index = ring slot of the vertex, q = quantum of its interior angle
+__device__ __forceinline__ P2 find_indention_vertex(FrontState &f, int index, int q, unsigned short *cb)
 {
     const int n = f.n, lane = lane_id();
     const int v = f.ringu[index], left = f.ringu[wrapi(index + 1, n)], right = f.ringu[wrapi(index - 1, n)];
@@ -752,20 +777,20 @@ __device__ __forceinline__ P2 find_indention_vertex(FrontState &f, int index, do
             const P2 a = ldc(f, p1), b = ldc(f, p2);
             const double A = b.x - a.x, B = b.y - a.y;
             const double den = A * A + B * B;
-            if (den == 0) {
-                zero_div = true;
-            } else {
-                const double s = (A * pv.x + B * pv.y - B * a.y - A * a.x) / den;
-                near = near || (0 <= s && s <= 1 && dist(pv, mkp(a.x + s * A, a.y + s * B)) <= d);
-            }
+            // C:647: a zero-length segment between two domain vertices raises (Python operands); with a generated end
+            // the quotient is NumPy's 0 / 0 = nan, `0 <= s <= 1` is False and the segment is not "inner"
+            zero_div = zero_div || (den == 0 && p1 < f.n0 && p2 < f.n0);
+            const double s = (A * pv.x + B * pv.y - B * a.y - A * a.x) / den;
+            near = near || (0 <= s && s <= 1 && dist(pv, mkp(a.x + s * A, a.y + s * B)) <= d);
         }
     }
-    // (the reference evaluates the vertex test first for all, then the segments in order: a zero-length segment raises
-    // only if it is reached, i.e. always -- both loops run to the end)
-    if (__ballot(zero_div) != 0ULL) { f.raised = true; return pv; }
+    // (both loops of the reference run to the end whatever they find: a raising segment is always reached)
+    if (__ballot(zero_div) != 0ULL) { f.raised = 1; return pv; }
     if (__ballot(near) == 0ULL) return pv;
+    const double cos_a = f.tab[kFtCosInd + q];
+    const bool np_A = v >= f.n0 || left >= f.n0;
     for (int times = 4; ; times++) {
-        const P2 nv = indention_vertex(f, pv, pl, pr, (360 - v_angle) / 2, d / times);
+        const P2 nv = indention_vertex(f, pv, pl, pr, cos_a, d / times, np_A);
         if (f.raised) return pv;
         if (times >= 10) return pv;
         const int nb = clockwise_vertices(f, v, cb);
@@ -775,9 +800,15 @@ __device__ __forceinline__ P2 find_indention_vertex(FrontState &f, int index, do
 
 // One wavefront per env: smooth_current_boundary_3 on the running episode's front.  code_out[env]: 0 done,
 // kSmoothSkipped / kSmoothLogOverflow / kSmoothDegree (untouched), kSmoothRaises (the reference raises: the vertices
-// moved before that point stay moved, as in the reference).
+// moved before that point stay moved, as in the reference), kSmoothNonFinite: a construction divided by a NumPy zero
+// (two coincident vertices, one of them generated), the nan position passed is_inside_boundary -- every comparison with
+// nan is False, so it passes exactly when the original position reads >= pi against every entry of its surrounding
+// polygon -- and the reference assigned it; it then raises in the find_next_state that follows (int(nan), C:1257).  The
+// kernel stops at that vertex; the usual outcome of a NumPy zero divisor is the other one: every trial is rejected and the
+// vertex stays where it is.
 __global__ void __launch_bounds__(64)
-k_smooth_front(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int32_t *__restrict__ code_out)
+k_smooth_front(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int32_t *__restrict__ code_out,
+               const double *__restrict__ tab)
 {
     extern __shared__ double2 smem[];
     const int env = blockIdx.x, lane = lane_id();
@@ -821,18 +852,21 @@ k_smooth_front(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int32
     }
     wave_sync();
     FrontState f;
-    f.coord = coord; f.adj = adj; f.deg = deg; f.ringu = ringu; f.n = n; f.raised = false;
+    f.coord = coord; f.adj = adj; f.deg = deg; f.ringu = ringu; f.n = n; f.n0 = n0; f.raised = 0; f.tab = tab;
     for (int i = 0; i < n && !f.raised; i++) {
         const int v = uniform_i32((int)ringu[i]);
         if (v < n0) continue;   // `in self.original_vertices`
         const int nxt = uniform_i32((int)ringu[i + 1 == n ? 0 : i + 1]), prv = uniform_i32((int)ringu[i == 0 ? n - 1 : i - 1]);
         const P2 pv = ldc(f, v), pn = ldc(f, nxt), pp = ldc(f, prv);
-        const double v_angle = rad2deg(cw(pv, pn, pp));
+        const double v_rad = cw(pv, pn, pp);
+        const double v_angle = rad2deg(v_rad);
+        const int q = min(max(uniform_i32(angle_q(v_rad)), 0), kFtQ - 1);
         P2 nw = pv;
         if (v_angle <= 90) {
             double target = v_angle >= 45 ? v_angle : 45;
-            for (int guard = 0; guard < 24; guard++) {
-                const P2 cand = middle_vertex(pv, pn, pp, target);
+            const int row = v_angle >= 45 ? min(max(q, kFtMidQ0), kFtMidQ1) - kFtMidQ0 + 1 : 0;
+            for (int k = 0; k < kFtMidSteps; k++) {   // target reaches 135 after at most 18 steps of 5
+                const P2 cand = middle_vertex(pv, pn, pp, tab[kFtTanMid + row * kFtMidSteps + k]);
                 if (target >= 135) break;
                 const int nb = clockwise_vertices(f, v, cb);
                 if (is_inside_boundary(f, pv, cand, cb, nb, nxt, prv)) { nw = cand; break; }
@@ -844,22 +878,25 @@ k_smooth_front(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int32
             const double right_angle = rad2deg(cw(pp, pv, ldc(f, nn_r)));
             if (right_angle < 45) nw = find_side_vertex(f, v, nxt, prv, nn_r, right_angle, cb);
             else if (left_angle < 45) nw = find_side_vertex(f, v, prv, nxt, nn_l, left_angle, cb);
-            else nw = find_indention_vertex(f, i, v_angle, cb);
+            else nw = find_indention_vertex(f, i, q, cb);
         } else if (v_angle <= 270) {
-            nw = find_indention_vertex(f, i, v_angle, cb);
+            nw = find_indention_vertex(f, i, q, cb);
         } else {
-            // inner_vertex(vertex, 45), M:865-880
+            // inner_vertex(vertex, 45), M:865-880 (A = vertex.x - m.x with a generated vertex: a NumPy divisor)
             const P2 m = mkp((pn.x + pp.x) / 2, (pn.y + pp.y) / 2);
-            const double d = dist(m, pp) * tan(deg2rad(45.0));
+            const double d = dist(m, pp) * tab[kFtTan45];
             const double A = pv.x - m.x, B = pv.y - m.y;
-            const double q = py_div(f, d * d, A * A + B * B);
+            const double qq = py_div(f, d * d, A * A + B * B, true);
+            const double s = py_sqrt(f, qq);
             if (f.raised) break;
-            const double s = sqrt(q);
-            if (lane == 0) coord[v] = make_double2(m.x + s * A, m.y + s * B);
+            const double ix = m.x + s * A, iy = m.y + s * B;
+            if (!(isfinite(ix) && isfinite(iy))) { f.raised = 2; break; }
+            if (lane == 0) coord[v] = make_double2(ix, iy);
             wave_sync();
-            nw = find_indention_vertex(f, i, v_angle, cb);
+            nw = find_indention_vertex(f, i, q, cb);
         }
         if (f.raised) break;
+        if (!(isfinite(nw.x) && isfinite(nw.y))) { f.raised = 2; break; }
         if (lane == 0) coord[v] = make_double2(nw.x, nw.y);
         wave_sync();
     }
@@ -873,7 +910,7 @@ k_smooth_front(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int32
             rxy[i] = c;
         }
     }
-    if (lane == 0) code_out[env] = f.raised ? kSmoothRaises : 0;
+    if (lane == 0) code_out[env] = f.raised == 2 ? kSmoothNonFinite : (f.raised ? kSmoothRaises : 0);
 }
 
 __host__ __device__ __forceinline__ size_t smooth_front_lds_bytes(int ring_cap, int log_cap)
@@ -1005,8 +1042,17 @@ __global__ void k_move_finish(DevState S, int cap, const uint8_t *__restrict__ m
         done[e] = 1;
         return;
     }
-    if (sw < 0) return;          // graph not rebuildable (log overflow): stays kMoveNeedsSmoothing, done = 1
     int32_t *m = nv_meta + (size_t)e * kNvMeta;
+    if (sw == kSmoothNonFinite) {
+        // the reference accepted a nan position: smooth_pave returns, B:416-422 run, then find_next_state raises (C:1257)
+        const int cnt = nv_count[e];
+        m[1] = cnt > 0 ? nv_gid[(size_t)e * cap] : 0; m[2] = cnt > 0 ? nv_gid[(size_t)e * cap + cnt - 1] : 0; m[3] = cnt; m[4] = m[0];
+        nv_count[e] = 0;
+        code[e] = (uint8_t)kMoveSmoothRaises;
+        done[e] = 1;
+        return;
+    }
+    if (sw < 0) return;          // graph not rebuildable (log overflow): stays kMoveNeedsSmoothing, done = 1
     const int cnt = nv_count[e], epoch = m[0];
     const int first = cnt > 0 ? nv_gid[(size_t)e * cap] : 0, last = cnt > 0 ? nv_gid[(size_t)e * cap + cnt - 1] : 0;
     bool dn = false;
