@@ -136,6 +136,13 @@ int meshenv_group_size(const MeshEnv *h);
  * (checks, workgroup barrier, updates dealt over the SIMDs), 2 = k_step_spec<G> (no barrier: an action that survives the
  * cheap exact tests is extracted speculatively by an idle wavefront while its checks finish). */
 int meshenv_step_kernel(const MeshEnv *h);
+/* The smoothing kernels evaluate `x ** 2` like the reference's libm (CPython's float ** 2 is pow(x, 2.0), which glibc does
+ * not round correctly: it differs from x * x in 0.085 % of the arguments) through a restatement of glibc's pow
+ * (csrc/meshenv_libm.h) that the library validates against the libm of the running process at the first smoothing call.
+ * Returns 1: validated, the smoothers square as the reference does; 0: this libm computes pow differently (or
+ * MESHENV_LIBM_EXACT=0 is set), the smoothers use x * x and agree with the reference to one ulp per squaring instead of
+ * bit for bit; -1: not checked yet (no smoothing call so far).  The reference has no counterpart: it IS that libm. */
+int meshenv_libm_exact(const MeshEnv *h);
 
 /*
  * reset(): rl/boundary_env.py:67-84 for every env whose mask byte is non-zero (all envs when

@@ -879,10 +879,11 @@ int meshenv_ref_move(RefEnv *e, const double *point, double type, float *obs, ui
             }
         }
     }
-    if (not_valid) { /* B:375-378; `reference_point not in list` is object identity: a ring vertex is listed once */
+    if (not_valid) { /* B:375-378; `reference_point not in list` is object identity (Vertex has no __eq__): compare ids --
+                      * a coincident twin of a listed vertex is another object and is appended as well */
         int listed = 0;
         for (int k = 0; k < e->n_nv; k++)
-            if (e->nv[k].x == reference_point.x && e->nv[k].y == reference_point.y) listed = 1;
+            if (e->nv_id[k] == e->rid[index]) listed = 1;
         if (!listed) {
             e->nv[e->n_nv] = reference_point;
             e->nv_id[e->n_nv++] = e->rid[index];
@@ -1504,6 +1505,9 @@ int meshenv_ref_smooth_front(RefEnv *e)
         e->ring[i] = nv;
     }
     free(f.g.adj); free(f.g.deg);
+    /* not_valid_points holds the Vertex objects themselves: a listed front vertex that moved is tested (M:428-433) at its
+     * new position from now on */
+    for (int k = 0; k < e->n_nv; k++) e->nv[k] = e->vtab[e->nv_id[k]];
     return f.raised == 2 ? -4 : (f.raised ? -3 : 0);
 }
 

@@ -43,6 +43,7 @@ EXPORTS = [
     "meshenv_actor_forward", "meshenv_actor_sample", "meshenv_get_last_episode", "meshenv_element_quality",
     "meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid", "meshenv_step_kernel",
     "meshenv_create_random", "meshenv_get_domain", "meshenv_smooth", "meshenv_smooth_final", "meshenv_get_not_valid_ids", "meshenv_step_actor",
+    "meshenv_libm_exact",
 ]
 
 
@@ -94,6 +95,8 @@ def load():
     L.meshenv_group_size.restype = C.c_int
     L.meshenv_step_kernel.argtypes = [vp]
     L.meshenv_step_kernel.restype = C.c_int
+    L.meshenv_libm_exact.argtypes = [vp]
+    L.meshenv_libm_exact.restype = C.c_int
     L.meshenv_reset.argtypes = [vp, u8p, f32p]
     L.meshenv_reset_static.argtypes = [vp, u8p, f32p, C.c_int]
     L.meshenv_move.argtypes = [vp, vp, vp, vp, vp, vp, vp]

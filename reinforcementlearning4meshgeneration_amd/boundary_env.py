@@ -20,17 +20,20 @@ from typing import Optional, Sequence
 import numpy as np
 
 from .domains import Point, read_polygon
-from .vec_env import MeshVecEnv, make_spaces
+from .vec_env import MeshVecEnv, make_spaces, smoothing_log_capacity
 
 
 class BoudaryEnv:  # the reference's spelling
-    # log_capacity: elements / generated vertices kept per episode (`generated_meshes`); 1024 keeps the smoothers'
-    # per-env graph (csrc/meshenv_smooth.h: ~60 B per logged vertex) inside one CU's 160 KB of LDS for rings up to ~1500
+    # log_capacity: elements / generated vertices kept per episode (`generated_meshes`).  Default: the largest value (up to
+    # 4096) for which the smoothers' per-env graph still fits one CU's 160 KB of LDS for this domain's ring
+    # (vec_env.smoothing_log_capacity: ~2700 for boundary(), ~2400 for the 272-vertex d3 ring); an episode that outgrows it
+    # keeps exact counts and rewards, but `generated_meshes` / exports are truncated (a RuntimeWarning says so) and
+    # smooth() / smooth_pave() refuse it.
     metadata = {"render.modes": ["human"]}
     TYPE_THRESHOLD = 0.3
 
     def __init__(self, boundary: Sequence[Point], experiment_version=None, env_name=None, *, device: int = 0,
-                 api: str = "legacy", log_capacity: int = 1024):
+                 api: str = "legacy", log_capacity: Optional[int] = None):
         if hasattr(boundary, "vertices"):  # a reference-style Boundary2D
             boundary = [(v.x, v.y) for v in boundary.vertices]
         if api not in ("legacy", "gymnasium"):
@@ -40,12 +43,15 @@ class BoudaryEnv:  # the reference's spelling
         self.experiment_version = experiment_version if experiment_version else "test"
         self.env_name = env_name if env_name is not None else 1
         self.observation_space, self.action_space = make_spaces()
+        if log_capacity is None:
+            log_capacity = smoothing_log_capacity(len(self.points))
         self._vec = MeshVecEnv([self.points], n_envs=1, device=device, auto_reset=False, log_capacity=log_capacity)
         self.original_area = self._vec.constants[0].original_area
         self.average_edge_length = self._vec.constants[0].average_edge_length
         self.estimated_area_range = (self._vec.constants[0].est_min_l, self._vec.constants[0].est_crit_l)
         self.neighbor_num, self.radius_num, self.radius = 6, 3, 4
-        self.history_info = {-1: [], 1: [], 0: []}
+        self.history_info = {-1: [], 1: [], 0: []}   # rl/boundary_env.py:61-65: reward of every accepted element, per rule
+        self._valid_seen = 0
         self.current_state = None
 
     @classmethod
@@ -54,7 +60,9 @@ class BoudaryEnv:  # the reference's spelling
         return cls(read_polygon(path), **kw)
 
     # ------------------------------------------------------------------ Gym surface
-    def reset(self, *, seed=None, static=False, options=None):
+    def reset(self, static=False, *, seed=None, options=None):
+        """rl/boundary_env.py:67 `reset(static=False)` (positional, as the legacy callers pass it) and the Gymnasium
+        keywords of v2/src/mesh_rl/envs/boundary_env.py:136."""
         if seed is not None and hasattr(self.action_space, "seed"):
             self.action_space.seed(seed)
         obs = self._vec.reset(static=bool(static)).cpu().numpy()[0].copy()
@@ -70,6 +78,15 @@ class BoudaryEnv:  # the reference's spelling
         reward = np.float64(rew.cpu()[0].item())
         done_b, comp_b = bool(done.cpu()[0]), bool(comp.cpu()[0])
         self.current_state = obs_np
+        # rl/boundary_env.py:229: `self.history_info[rule].append(reward)` on an accepted element, before the +10 of a
+        # finished ring is added (:232); rule by the thresholds of :144-186 (a rule-0 action that reuses an existing vertex
+        # stays rule 0).  The +10 is taken off again here, which can cost the last bit of that one entry.
+        valid_now = self._vec.counters()["valid"]
+        if valid_now > self._valid_seen:
+            a0 = float(np.asarray(action, dtype=np.float32).reshape(-1)[0])
+            rule = -1 if a0 <= -0.5 else (1 if a0 >= 0.5 else 0)
+            self.history_info[rule].append(np.float64(reward - 10) if (done_b and comp_b) else reward)
+        self._valid_seen = valid_now
         info = {"is_complete": comp_b}
         if self.api == "gymnasium":
             return obs_np, reward, done_b and comp_b, done_b and not comp_b, info

@@ -50,6 +50,7 @@ struct MeshEnv {
     int32_t *front_code = nullptr;     // [E] outcome of the front smoother (gates the interior pass of the same call)
     double *front_tab = nullptr;       // [kFtTotal] the front smoother's tan / cos values from the host's libm
     bool smooth_ready = false, move_ready = false;   // set only after every allocation / attribute call succeeded
+    int libm_exact = -1;               // pow2_glibc == the running libm's pow(x, 2.0) on the validation set (-1: not checked yet)
     Reselect *pend = nullptr;          // [E] selection parked by the candidate rebuild (csrc/meshenv_smooth.h)
     float *pend_obs = nullptr;         // [E][18]
     bool reselect_pending = false;     // a rebuild ran since the last step kernel
@@ -503,6 +504,7 @@ int meshenv_num_envs(const MeshEnv *h) { return h ? h->n_envs : MESHENV_E_ARG; }
 int meshenv_max_ring(const MeshEnv *h) { return h ? h->max_ring : MESHENV_E_ARG; }
 int meshenv_group_size(const MeshEnv *h) { return h ? h->group : MESHENV_E_ARG; }
 int meshenv_step_kernel(const MeshEnv *h) { return h ? (h->group > 1 ? (h->spec ? 2 : 1) : 0) : MESHENV_E_ARG; }
+int meshenv_libm_exact(const MeshEnv *h) { return h ? h->libm_exact : MESHENV_E_ARG; }
 
 int meshenv_reset_static(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev, int is_static)
 {
@@ -539,13 +541,59 @@ static void fill_front_tables(std::vector<double> &t)
             target += 5;
         }
     }
+    // get_radius_points' bisector (general/components.py:1227-1237): math.cos / math.sin of theta / 2 and of the rotation angle
+    for (int q = 0; q < kFtQ; q++) {
+        const double a = (double)q / 1e4;
+        t[kFtSinCosFull + 2 * q] = std::sin(a);
+        t[kFtSinCosFull + 2 * q + 1] = std::cos(a);
+        t[kFtSinCosHalf + 2 * q] = std::sin(a / 2);
+        t[kFtSinCosHalf + 2 * q + 1] = std::cos(a / 2);
+    }
+}
+
+// csrc/meshenv_libm.h against the libm of this process: 2^18 arguments m * 2^e, m in [1, 2), e in [-40, 24], both signs
+// (the range of coordinate differences and of the quadratic formulas' terms), plus the exact powers of two.
+static int validate_pow2()
+{
+    volatile double two = 2.0;   // keeps the compiler from turning pow(x, 2) into x * x
+    unsigned long long s = 88172645463325252ULL;
+    for (int n = 0; n < (1 << 18); n++) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double m = 1.0 + (double)(s >> 12) / 4503599627370496.0;
+        double x = std::ldexp(n < 128 ? 1.0 : m, (int)((s >> 3) % 65) - 40);
+        if (s & 1) x = -x;
+        if (std::pow(x, two) != pow2_glibc(x)) return 0;
+    }
+    return 1;
+}
+
+// the host-libm table and the pow2 validation, on first use (the smoothing entry points and meshenv_move)
+static int ensure_libm_tables(MeshEnv *h)
+{
+    if (h->front_tab) return MESHENV_OK;
+    MESHENV_ON_DEVICE(h);
+    if (h->libm_exact < 0) {
+        const char *off = std::getenv("MESHENV_LIBM_EXACT");   // "0": square exactly (x * x) whatever the libm does
+        h->libm_exact = (off && off[0] == '0') ? 0 : validate_pow2();
+    }
+    double *tab_dev = nullptr;
+    const int rc = dev_alloc(h, &tab_dev, (size_t)kFtTotal);
+    if (rc != MESHENV_OK) return rc;
+    std::vector<double> tab;
+    fill_front_tables(tab);
+    // synchronous copy from pageable memory: the vector goes out of scope right after
+    HIP_TRY(h, hipMemcpy(tab_dev, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+    h->front_tab = tab_dev;   // only now: a failed copy leaves "no table" and the next call tries again
+    return MESHENV_OK;
 }
 
 // buffers and kernel attributes of the smoothing entry points, on first use
 static int ensure_smooth_state(MeshEnv *h)
 {
     if (h->smooth_ready) return MESHENV_OK;
-    int rc = MESHENV_OK;
+    MESHENV_ON_DEVICE(h);
+    int rc = ensure_libm_tables(h);
+    if (rc != MESHENV_OK) return rc;
     if (!h->smooth_sweeps) rc = dev_alloc(h, &h->smooth_sweeps, (size_t)h->n_envs);
     if (rc != MESHENV_OK) return rc;
     if (!h->front_code) rc = dev_alloc(h, &h->front_code, (size_t)h->n_envs);
@@ -560,16 +608,16 @@ static int ensure_smooth_state(MeshEnv *h)
     if (!h->pend_obs) rc = dev_alloc(h, &h->pend_obs, (size_t)h->n_envs * kObsDim);
     if (rc != MESHENV_OK) return rc;
     HIP_TRY(h, hipMemsetAsync(h->pend, 0xff, sizeof(Reselect) * (size_t)h->n_envs, h->stream));   // n_elem = -1: nothing parked
-    if (!h->front_tab) rc = dev_alloc(h, &h->front_tab, (size_t)kFtTotal);
-    if (rc != MESHENV_OK) return rc;
-    {
-        std::vector<double> tab;
-        fill_front_tables(tab);
-        // synchronous copy from pageable memory: the vector may go out of scope right after
-        HIP_TRY(h, hipMemcpy(h->front_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
-    }
     h->smooth_ready = true;   // only now: a failure above leaves the state "not ready" and the next call tries again
     return MESHENV_OK;
+}
+
+static LibmRef libm_ref(const MeshEnv *h)
+{
+    LibmRef lr;
+    lr.tab = h->front_tab;   // nullptr until ensure_smooth_state ran: find_next_state then evaluates with ocml
+    lr.exact = h->libm_exact > 0 ? 1 : 0;
+    return lr;
 }
 
 // smooth_pave(interior=False) + find_next_state(static = is_static) for the envs of `mask_dev`; sw: [E] outcome
@@ -580,17 +628,18 @@ static int launch_full_smoothing(MeshEnv *h, const uint8_t *mask_dev, int iterat
     const int log_cap = h->S.prm.log_cap;
     const dim3 grid(h->n_envs), block(64);
     hipLaunchKernelGGL(k_smooth_front, grid, block, smooth_front_lds_bytes(h->cap, log_cap), h->stream, h->S, h->cap, mask_dev,
-                       h->front_code, (const double *)h->front_tab);
+                       h->front_code, (const double *)h->front_tab, h->libm_exact, h->move_ready ? h->nv_xy : nullptr,
+                       (const int32_t *)h->nv_count, (const int32_t *)h->nv_gid);
     HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(k_smooth_interior, grid, block, smooth_lds_bytes(h->cap, log_cap), h->stream, h->S, h->cap, 0, mask_dev,
                        h->front_code, iteration, sw, diff_dev);
     HIP_TRY(h, hipGetLastError());
     if (is_static)
         hipLaunchKernelGGL(k_rebuild_candidates<2>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
-                           obs_dev);
+                           obs_dev, libm_ref(h));
     else
         hipLaunchKernelGGL(k_rebuild_candidates<1>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
-                           obs_dev);
+                           obs_dev, libm_ref(h));
     HIP_TRY(h, hipGetLastError());
     return MESHENV_OK;
 }
@@ -633,10 +682,11 @@ int meshenv_move(MeshEnv *h, const double *points_dev, const double *type_dev, f
     if (!points_dev || !type_dev || !obs_dev || !done_dev || !complete_dev || !code_dev) return fail_arg(h, "meshenv_move: null device pointer");
     if (move_lds_bytes(h->cap) > 160 * 1024) return fail_arg(h, "meshenv_move: ring too long for the move kernel's LDS (60 B per vertex)");
     MESHENV_ON_DEVICE(h);
-    const int rc = ensure_move_state(h);
+    int rc = ensure_move_state(h);
+    if (rc == MESHENV_OK) rc = ensure_libm_tables(h);   // before the first k_move: every move computes its observation alike
     if (rc != MESHENV_OK) return rc;
     hipLaunchKernelGGL(k_move, dim3(h->n_envs), dim3(64), move_lds_bytes(h->cap), h->stream, h->S, h->cap, points_dev, type_dev,
-                       obs_dev, done_dev, complete_dev, code_dev, h->nv_xy, h->nv_count, h->nv_gid);
+                       obs_dev, done_dev, complete_dev, code_dev, h->nv_xy, h->nv_count, h->nv_gid, libm_ref(h));
     HIP_TRY(h, hipGetLastError());
     if (smoothing_fits(h, true)) {
         // B:405-426: the envs k_move left at "no selectable reference vertex" go through smooth_pave and select again
@@ -686,7 +736,7 @@ int meshenv_smooth(MeshEnv *h, int which, const uint8_t *mask_dev, int iteration
     HIP_TRY(h, hipGetLastError());
     if (which) return MESHENV_OK;   // an archived mesh: nothing to step on, no candidate list
     hipLaunchKernelGGL(k_rebuild_candidates<0>, grid, block, h->lds, h->stream, h->S, h->cap, mask_dev, sw, h->pend, h->pend_obs,
-                       (float *)nullptr);
+                       (float *)nullptr, libm_ref(h));
     HIP_TRY(h, hipGetLastError());
     h->reselect_pending = true;
     return MESHENV_OK;
@@ -1048,7 +1098,7 @@ int meshenv_debug_stamps(MeshEnv *h, uint64_t *out_host)
 
 // ---- primitive self-test hook (tests/test_gpu_primitives.py): evaluates the device geometry primitives on
 // caller-supplied host arrays so that they can be compared with the CPU oracle's.
-__global__ void k_selftest(int what, int n, const double *in, double *out)
+__global__ void k_selftest(int what, int n, const double *in, double *out, int libm_exact)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1073,11 +1123,11 @@ __global__ void k_selftest(int what, int n, const double *in, double *out)
         // by math.tan(math.radians(angle / 2)) (which 0) or math.cos(math.radians(angle)) (which 1, 2) before the upload.
         const double *q = in + 9 * (size_t)i;
         FrontState f;
-        f.coord = nullptr; f.adj = nullptr; f.deg = nullptr; f.ringu = nullptr; f.n = 0; f.n0 = 0; f.raised = 0; f.tab = nullptr;
+        f.coord = nullptr; f.adj = nullptr; f.deg = nullptr; f.ringu = nullptr; f.n = 0; f.n0 = 0; f.raised = 0; f.tab = nullptr; f.exact = libm_exact != 0;
         const P2 v = mkp(q[1], q[2]), a = mkp(q[3], q[4]), b = mkp(q[5], q[6]);
         const int which = (int)q[0];
         P2 r;
-        if (which == 0) r = middle_vertex(v, a, b, q[7]);
+        if (which == 0) r = middle_vertex(f, v, a, b, q[7]);
         else if (which == 1) r = side_vertex(f, v, a, b, q[7], q[8], false);
         else if (which == 2) r = indention_vertex(f, v, a, b, q[7], q[8], false);
         else {  // 3: Mesh.estimate_4th_vertex(origin, left, right, factor, suggest_dist or < 0 for None)
@@ -1085,7 +1135,7 @@ __global__ void k_selftest(int what, int n, const double *in, double *out)
             r = mkp(e.x, e.y);
         }
         out[i] = f.raised ? __builtin_nan("") : (what == 9 ? r.x : r.y);
-    }
+    } else if (what == 11) out[i] = pow2_glibc(in[i]);   // against the host libm's pow(x, 2.0)
 }
 
 int meshenv_selftest(int device, int what, int n, int in_per_item, const double *in_host, double *out_host)
@@ -1112,7 +1162,8 @@ int meshenv_selftest(int device, int what, int n, int in_per_item, const double 
     }
     if (hipMemcpy(din, in_host, sizeof(double) * (size_t)n * in_per_item, hipMemcpyHostToDevice) != hipSuccess) rc = MESHENV_E_HIP;
     if (rc == MESHENV_OK) {
-        hipLaunchKernelGGL(k_selftest, dim3((n + 63) / 64), dim3(64), 0, nullptr, what, n, din, dout);
+        hipLaunchKernelGGL(k_selftest, dim3((n + 63) / 64), dim3(64), 0, nullptr, what, n, din, dout,
+                           (what == 9 || what == 10) ? validate_pow2() : 0);
         if (hipDeviceSynchronize() != hipSuccess) rc = MESHENV_E_HIP;
     }
     if (rc == MESHENV_OK && hipMemcpy(out_host, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = MESHENV_E_HIP;

@@ -17,6 +17,7 @@
 #pragma once
 
 #include "meshenv_geom.h"
+#include "meshenv_libm.h"
 #include "meshenv_state.h"
 
 namespace meshenv {
@@ -376,8 +377,16 @@ struct BqArgs {
 // Updates c.ref, c.bl, c.ct/st (action frame of the new state), c.obs (lanes 0..17), c.status; fills bq outputs.
 // (is_static / nv: compile-time constants at every call; the move() API passes PointEnvironment(static=True) and its
 // not_valid_points list, C:1213-1218, M:284-288)
+// (lr: the move() / smoothing kernels only -- squares and the bisector's sines / cosines as the reference's libm gives
+// them, csrc/meshenv_libm.h; the step kernels pass none and compile to what they were)
+__device__ __forceinline__ double dist_lr(const LibmRef lr, P2 a, P2 b)
+{
+    if (lr.tab == nullptr || !lr.exact) return dist(a, b);
+    return sqrt_pos(pow2_nc(a.x - b.x) + pow2_nc(a.y - b.y));
+}
+
 __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArgs &bq, const bool is_static = false,
-                                                const double2 *nv = nullptr, int n_nv = 0)
+                                                const double2 *nv = nullptr, int n_nv = 0, const LibmRef lr = LibmRef{nullptr, 0})
 {
     const Params &p = S.prm;
     const int lane = c.lane, n = c.n;
@@ -420,7 +429,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         ib = lane == 8 ? (m1 ? wrapi(bqa + 1, n) : (m2 ? bq.b : ib)) : ib;
         ib = (lane == 9 && m1) ? wrapi(bqa - 1, n) : ib;
     }
-    const double dv = dist(ldp(c, ia), ldp(c, ib));
+    const double dv = dist_lr(lr, ldp(c, ia), ldp(c, ib));
     // atan2 jobs.  lanes 1..5: cw(ref; v, right); lane 0: cw(ref; right, ref + (1, 0)); lane 6: atan2(right - ref);
     // lanes 7..63: the clockwise angle of traversal position ord = lane - 7 of the observation scan (stage C only
     // evaluates atan2 itself for rings longer than 58), so stages A and C share one transcendental pass.
@@ -473,6 +482,13 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         const SinCos sc = sincos_nc(arg);
         sj = sc.s;
         cj = sc.c;
+    }
+    if (lr.tab != nullptr && lane < 2) {
+        // theta and the rotation angle are quantised: their sines / cosines from the host libm's table (lane 0: theta / 2)
+        const int q = min(max(angle_q(lane == 0 ? theta : rot), 0), kFtQ - 1);
+        const double *e = lr.tab + (lane == 0 ? kFtSinCosHalf : kFtSinCosFull) + 2 * q;
+        sj = e[0];
+        cj = e[1];
     }
     if (bq.mode != 0) {
         bq.mesh_area = uniform_f64(bq.half01 * lane_f64(sj, 3) + bq.half23 * lane_f64(sj, 4));
@@ -549,7 +565,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         }
         const bool live = in_range && ii != i_right && ii != i_left && angle != 0.0;
         if (live) {
-            const double d = dist(ref, v);
+            const double d = dist_lr(lr, ref, v);
             const double kf = angle / third;
             if (kf < 3.0 && d < target_length) {
                 const int k = (int)kf;
@@ -573,7 +589,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
             const double s = num / den;
             const double h = hx ? (ry + s * uy) / wy : (rx + s * ux) / wx;
             if (have && 0.0 < s && s < 1.0 && 0.0 < h && h < 1.0) {
-                const double val = (dist(ref, mkp(ref.x + s * ux, ref.y + s * uy)) / radius) / bl;
+                const double val = (dist_lr(lr, ref, mkp(ref.x + s * ux, ref.y + s * uy)) / radius) / bl;
                 if (val < rbest) { rbest = val; rord = ord; }
             }
         }
@@ -611,7 +627,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         float fa = (float)fmin(((2 * j + 1) * theta) / 6, clipmax);  // default [1, clip((2j+1)*theta/6)]
         if (use_hit) {
             const int ov = (int)ro + 1 - j;  // ring[_i - 1 + j] in traversal order
-            fd = (float)((dist(ref, ldp(c, wrapi(idc - 1 - ov, n))) / radius) / bl);
+            fd = (float)((dist_lr(lr, ref, ldp(c, wrapi(idc - 1 - ov, n))) / radius) / bl);
             fa = (float)c.ang_ord[ov];
         } else if (sw < 1.0f) {
             fd = sw;
@@ -1241,7 +1257,8 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
 // (is_move: move() extracts the element without reward, current_area or failed_num bookkeeping and observes with
 // static=True and its not_valid_points, B:328-345)
 __device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d, volatile int *upd_done = nullptr,
-                                          const bool is_move = false, const double2 *nv = nullptr, int n_nv = 0)
+                                          const bool is_move = false, const double2 *nv = nullptr, int n_nv = 0,
+                                          const LibmRef lr = LibmRef{nullptr, 0})
 {
     const bool has_helper = upd_done != nullptr;
     const Params &prm = S.prm;
@@ -1349,7 +1366,7 @@ __device__ __forceinline__ void env_apply(Ctx &c, const DevState &S, Decision &d
     if (is_move) {
         bq.mode = 0;
         bq.skip = false;
-        find_next_state(c, S, bq, true, nv, n_nv);
+        find_next_state(c, S, bq, true, nv, n_nv, lr);
     } else {
         find_next_state(c, S, bq);
     }
@@ -1768,7 +1785,7 @@ __global__ void __launch_bounds__(64) k_move(DevState S, int cap, const double *
                                               const double *__restrict__ types, float *__restrict__ obs_out,
                                               uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
                                               uint8_t *__restrict__ code, double2 *__restrict__ nv_xy,
-                                              int32_t *__restrict__ nv_count, int32_t *__restrict__ nv_gid)
+                                              int32_t *__restrict__ nv_count, int32_t *__restrict__ nv_gid, const LibmRef lr)
 {
     extern __shared__ double2 smem[];
     Ctx c;
@@ -1792,12 +1809,15 @@ __global__ void __launch_bounds__(64) k_move(DevState S, int cap, const double *
     const int refgid = c.id[c.ref];     // ... and its identity (the reference's list holds Vertex objects)
     Decision d = env_check(c, S, 0.0f, 0.0f, 0.0f, false, true, mv_r, mv_a, mv_type);
     if (d.ok) {
-        env_apply(c, S, d, nullptr, true, nv, n_nv);  // B:345: the selection still sees the old not_valid_points
+        env_apply(c, S, d, nullptr, true, nv, n_nv, lr);  // B:345: the selection still sees the old not_valid_points
         n_nv = 0;                                     // B:365
     } else {
-        // B:359-361: `reference_point not in not_valid_points` is object identity -- a ring vertex is listed once
+        // B:359-361: `reference_point not in not_valid_points` is object identity (Vertex defines no __eq__): the test is
+        // on the vertex ids -- a coincident twin of a listed vertex (self-touching fronts have them) is a different object
+        // and is listed too
         bool listed = false;
-        for (int k = lane; k < n_nv; k += 64) listed = listed || (nv[k].x == refpt.x && nv[k].y == refpt.y);
+        const int32_t *gids = nv_gid + (size_t)env * cap;
+        for (int k = lane; k < n_nv; k += 64) listed = listed || gids[k] == refgid;
         if (__ballot(listed) == 0ULL) {
             if (lane == 0) {
                 nv[n_nv] = refpt;
@@ -1810,7 +1830,7 @@ __global__ void __launch_bounds__(64) k_move(DevState S, int cap, const double *
         BqArgs bq;
         bq.skip = false;
         bq.mode = 0; bq.a = 0; bq.b = 0; bq.ang0 = 0; bq.ang1 = 0; bq.q_ang0 = 0; bq.q_ang2 = 0; bq.half01 = 0; bq.half23 = 0;
-        find_next_state(c, S, bq, true, nv, n_nv);
+        find_next_state(c, S, bq, true, nv, n_nv, lr);
         c.ring_dirty = true;  // reference vertex, base length, action frame and observation moved: full record write-back
     }
     const bool none = c.ref < 0;
@@ -2025,7 +2045,10 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
 #ifdef MESHENV_NO_HELPER
     const bool helpers = false;
 #else
-    const bool helpers = balanced && G >= 4 && 2 * m <= G;
+#ifndef MESHENV_HELPER_MAX_M
+#define MESHENV_HELPER_MAX_M 8
+#endif
+    const bool helpers = balanced && G >= 4 && 2 * m <= G && m <= MESHENV_HELPER_MAX_M;
 #endif
     if (balanced && G >= 4) {
         const int r = __popc(mine & ((1u << wave) - 1u));  // my rank among the waves of my SIMD

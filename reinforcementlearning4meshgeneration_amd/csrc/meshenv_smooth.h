@@ -534,21 +534,6 @@ k_smooth_final(DevState S, int ring_cap, int which, const uint8_t *__restrict__ 
 // atan2-heavy inner loops -- one lane per entry of the surrounding polygon in is_inside_boundary, one lane per front
 // vertex / segment in find_indention_vertex's proximity tests.  Graph and coordinates as in k_smooth_final.
 
-// Every tan / cos of the front smoother has an argument derived from a QUANTISED angle (to_find_clockwise_angle rounds to
-// 1e-4 rad: 62 833 possible values) or from a literal, so the values the reference's libm returns are a finite table.
-// The host fills it with its own libm at the first smoothing call (fill_front_tables, csrc/meshenv_hip.hip) -- the libm
-// the reference's math.tan / math.cos call in the same process -- and the kernel reads it: bit-identical to the reference
-// by construction, where ocml's tan / cos differ from glibc's in the last bit of ~10 % of the arguments.
-//   [kFtCosInd + q]            cos(radians((360 - degrees(q e-4)) / 2))       indention_vertex, M:1048 / 886
-//   [kFtTan45]                 tan(radians(45))                               inner_vertex, M:872
-//   [kFtCosSide + k]           cos(radians(45 - 5 k)), k = 0..9               side_vertex via find_side_vertex, M:919-934
-//   [kFtTanMid + 19 row + k]   tan(radians(t_k / 2)), t_0 = 45 (row 0) or degrees(q e-4) >= 45 (row q - kFtMidQ0 + 1),
-//                              t_{k+1} = t_k + 5                              middle_vertex, M:809 with M:953-972
-constexpr int kFtQ = 62833;
-constexpr int kFtCosInd = 0, kFtTan45 = kFtQ, kFtCosSide = kFtQ + 1, kFtTanMid = kFtQ + 16;
-constexpr int kFtMidQ0 = 7853, kFtMidQ1 = 15709, kFtMidSteps = 19;
-constexpr int kFtTotal = kFtTanMid + (kFtMidQ1 - kFtMidQ0 + 2) * kFtMidSteps;
-
 struct FrontState {
     double2 *coord;
     const unsigned short *adj;
@@ -556,6 +541,7 @@ struct FrontState {
     const unsigned short *ringu;
     const double *tab;   // the table above
     int n, n0;
+    bool exact;    // pow2_glibc reproduces the running libm's pow(x, 2.0) (validated by the host): square like the reference
     int raised;    // 1: the reference raises here (math.sqrt of a negative number, a zero divisor between Python operands);
                    // 2: a construction with a NumPy zero divisor produced nan and the reference ACCEPTED it (see k_smooth_front)
 };
@@ -564,6 +550,13 @@ __device__ __forceinline__ P2 ldc(const FrontState &f, int v)
 {
     const double2 c = f.coord[v];
     return mkp(c.x, c.y);
+}
+
+// x ** 2 and Point2D.distance_to as the reference's libm evaluates them (csrc/meshenv_libm.h)
+__device__ __forceinline__ double sq(const FrontState &f, double v) { return f.exact ? pow2_nc(v) : v * v; }
+__device__ __forceinline__ double distf(const FrontState &f, P2 a, P2 b)
+{
+    return sqrt_pos(sq(f, a.x - b.x) + sq(f, a.y - b.y));
 }
 
 __device__ __forceinline__ double py_sqrt(FrontState &f, double v)
@@ -584,29 +577,27 @@ __device__ __forceinline__ double py_div(FrontState &f, double a, double b, bool
 __device__ __forceinline__ double deg2rad(double a) { return a * (kPi / 180.0); }   // math.radians
 __device__ __forceinline__ double rad2deg(double a) { return a * (180.0 / kPi); }   // math.degrees
 
-// quantum index of a clockwise angle (the angle is the double nearest to q e-4)
-__device__ __forceinline__ int angle_q(double a) { return (int)rint(a * 1e4); }
-
 // the two intersections of the circle |p - (a, b)| = dist with the line A x + B y = W + A a + B b, M:841-858 / 889-904
 __device__ __forceinline__ void circle_line(FrontState &f, double a, double b, double A, double B, double W, double dist_,
                                             bool np_A, P2 &v1, P2 &v2)
 {
     if (B == 0) {
         const double wa = py_div(f, W, A, np_A);   // W is a Python float (products of math.sqrt / math.cos results)
-        const double r = py_sqrt(f, dist_ * dist_ - wa * wa);
+        const double r = py_sqrt(f, sq(f, dist_) - sq(f, wa));
         v1 = mkp(wa + a, b + r);
         v2 = mkp(wa + a, b - r);
     } else if (A == 0) {
         const double wb = W / B;
-        const double r = py_sqrt(f, dist_ * dist_ - wb * wb);
+        const double r = py_sqrt(f, sq(f, dist_) - sq(f, wb));
         v1 = mkp(a + r, wb + b);
         v2 = mkp(a - r, wb + b);
     } else {
         const double M = -A / B;
         const double N = (W + A * a + B * b) / B;
         const double t = 2 * M * b - 2 * M * N + 2 * a;
-        const double disc = fabs(t * t - 4 * (M * M + 1) * ((N - b) * (N - b) + a * a - dist_ * dist_));
-        const double den = 2 * (M * M + 1);
+        const double m2 = sq(f, M);
+        const double disc = fabs(sq(f, t) - 4 * (m2 + 1) * (sq(f, N - b) + sq(f, a) - sq(f, dist_)));
+        const double den = 2 * (m2 + 1);
         const double sq = sqrt(disc);
         v1.x = (t + sq) / den;
         v2.x = (t - sq) / den;
@@ -616,11 +607,11 @@ __device__ __forceinline__ void circle_line(FrontState &f, double a, double b, d
 }
 
 // M:805-832; tan_half = math.tan(math.radians(target_angle / 2)) from the table
-__device__ __forceinline__ P2 middle_vertex(P2 vertex, P2 left, P2 right, double tan_half)
+__device__ __forceinline__ P2 middle_vertex(const FrontState &f, P2 vertex, P2 left, P2 right, double tan_half)
 {
     const P2 m = mkp((left.x + right.x) / 2, (left.y + right.y) / 2);
     const double A = right.x - left.x, B = right.y - left.y;
-    const double D = dist(left, m) / tan_half;
+    const double D = distf(f, left, m) / tan_half;
     P2 v1, v2;
     if (B == 0) {
         v1 = mkp(m.x, m.y + D);
@@ -632,30 +623,31 @@ __device__ __forceinline__ P2 middle_vertex(P2 vertex, P2 left, P2 right, double
         const double M = -A / B;
         const double N = A * m.x / B + m.y;
         const double t = -2 * M * N + 2 * m.x + 2 * M * m.y;
-        const double disc = fabs(t * t - 4 * (M * M + 1) * ((N - m.y) * (N - m.y) + m.x * m.x - D * D));
-        const double den = 2 * (M * M + 1);
+        const double m2 = sq(f, M);
+        const double disc = fabs(sq(f, t) - 4 * (m2 + 1) * (sq(f, N - m.y) + sq(f, m.x) - sq(f, D)));
+        const double den = 2 * (m2 + 1);
         const double sq = sqrt(disc);
         v1.x = (t + sq) / den;
         v2.x = (t - sq) / den;
         v1.y = M * v1.x + N;
         v2.y = M * v2.x + N;
     }
-    return dist(v1, vertex) < dist(v2, vertex) ? v1 : v2;
+    return distf(f, v1, vertex) < distf(f, v2, vertex) ? v1 : v2;
 }
 
 // M:834-863; cos_a = math.cos(math.radians(angle)) from the table
 __device__ __forceinline__ P2 side_vertex(FrontState &f, P2 vertex, P2 next_v, P2 nn_v, double cos_a, double d, bool np_A)
 {
-    const double W = d * dist(next_v, nn_v) * cos_a;
+    const double W = d * distf(f, next_v, nn_v) * cos_a;
     P2 v1, v2;
     circle_line(f, next_v.x, next_v.y, nn_v.x - next_v.x, nn_v.y - next_v.y, W, d, np_A, v1, v2);
-    return dist(v1, vertex) < dist(v2, vertex) ? v1 : v2;
+    return distf(f, v1, vertex) < distf(f, v2, vertex) ? v1 : v2;
 }
 
 // M:882-909
 __device__ __forceinline__ P2 indention_vertex(FrontState &f, P2 vertex, P2 left, P2 right, double cos_a, double d, bool np_A)
 {
-    const double W = d * dist(vertex, left) * cos_a;
+    const double W = d * distf(f, vertex, left) * cos_a;
     P2 v1, v2;
     circle_line(f, vertex.x, vertex.y, left.x - vertex.x, left.y - vertex.y, W, d, np_A, v1, v2);
     if (f.raised) return vertex;
@@ -744,7 +736,7 @@ __device__ __forceinline__ P2 find_side_vertex(FrontState &f, int v, int _next, 
                                                unsigned short *cb)
 {
     const P2 pv = ldc(f, v), pn = ldc(f, next), pnn = ldc(f, nn);
-    const double d = (dist(pv, ldc(f, _next)) + dist(pv, pn) + dist(pn, pnn)) / 3;
+    const double d = (distf(f, pv, ldc(f, _next)) + distf(f, pv, pn) + distf(f, pn, pnn)) / 3;
     const bool np_A = next >= f.n0 || nn >= f.n0;
     double target = 45;
     for (int k = 0; k < 10; k++) {   // target = 45 - 5 k reaches 0 <= v_angle at k = 9 at the latest
@@ -765,23 +757,23 @@ __device__ __forceinline__ P2 find_indention_vertex(FrontState &f, int index, in
     const int v = f.ringu[index], left = f.ringu[wrapi(index + 1, n)], right = f.ringu[wrapi(index - 1, n)];
     const int l2 = f.ringu[wrapi(index + 2, n)], r2 = f.ringu[wrapi(index - 2, n)];
     const P2 pv = ldc(f, v), pl = ldc(f, left), pr = ldc(f, right);
-    const double d = (dist(pv, pl) + dist(pv, pr)) / 2;
+    const double d = (distf(f, pv, pl) + distf(f, pv, pr)) / 2;
     bool near = false, zero_div = false;
     for (int i = lane; i < n; i += 64) {
         // Boundary2D.get_closet_points(front, vertex, [r2, right, left, l2], d): any other front vertex within d
         const int w = f.ringu[i];
-        if (!(w == v || w == r2 || w == right || w == left || w == l2)) near = near || dist(pv, ldc(f, w)) <= d;
+        if (!(w == v || w == r2 || w == right || w == left || w == l2)) near = near || distf(f, pv, ldc(f, w)) <= d;
         // find_closest_segments, M:1103-1112: a front segment not at the vertex whose foot point lies inside it, within d
         const int p1 = f.ringu[i == 0 ? n - 1 : i - 1], p2 = w;
         if (p1 != v && p2 != v) {
             const P2 a = ldc(f, p1), b = ldc(f, p2);
             const double A = b.x - a.x, B = b.y - a.y;
-            const double den = A * A + B * B;
+            const double den = sq(f, A) + sq(f, B);
             // C:647: a zero-length segment between two domain vertices raises (Python operands); with a generated end
             // the quotient is NumPy's 0 / 0 = nan, `0 <= s <= 1` is False and the segment is not "inner"
             zero_div = zero_div || (den == 0 && p1 < f.n0 && p2 < f.n0);
             const double s = (A * pv.x + B * pv.y - B * a.y - A * a.x) / den;
-            near = near || (0 <= s && s <= 1 && dist(pv, mkp(a.x + s * A, a.y + s * B)) <= d);
+            near = near || (0 <= s && s <= 1 && distf(f, pv, mkp(a.x + s * A, a.y + s * B)) <= d);
         }
     }
     // (both loops of the reference run to the end whatever they find: a raising segment is always reached)
@@ -808,7 +800,8 @@ __device__ __forceinline__ P2 find_indention_vertex(FrontState &f, int index, in
 // vertex stays where it is.
 __global__ void __launch_bounds__(64)
 k_smooth_front(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int32_t *__restrict__ code_out,
-               const double *__restrict__ tab)
+               const double *__restrict__ tab, int libm_exact, double2 *__restrict__ nv_xy, const int32_t *__restrict__ nv_count,
+               const int32_t *__restrict__ nv_gid)
 {
     extern __shared__ double2 smem[];
     const int env = blockIdx.x, lane = lane_id();
@@ -852,7 +845,7 @@ k_smooth_front(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int32
     }
     wave_sync();
     FrontState f;
-    f.coord = coord; f.adj = adj; f.deg = deg; f.ringu = ringu; f.n = n; f.n0 = n0; f.raised = 0; f.tab = tab;
+    f.coord = coord; f.adj = adj; f.deg = deg; f.ringu = ringu; f.n = n; f.n0 = n0; f.raised = 0; f.tab = tab; f.exact = libm_exact != 0;
     for (int i = 0; i < n && !f.raised; i++) {
         const int v = uniform_i32((int)ringu[i]);
         if (v < n0) continue;   // `in self.original_vertices`
@@ -866,7 +859,7 @@ k_smooth_front(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int32
             double target = v_angle >= 45 ? v_angle : 45;
             const int row = v_angle >= 45 ? min(max(q, kFtMidQ0), kFtMidQ1) - kFtMidQ0 + 1 : 0;
             for (int k = 0; k < kFtMidSteps; k++) {   // target reaches 135 after at most 18 steps of 5
-                const P2 cand = middle_vertex(pv, pn, pp, tab[kFtTanMid + row * kFtMidSteps + k]);
+                const P2 cand = middle_vertex(f, pv, pn, pp, tab[kFtTanMid + row * kFtMidSteps + k]);
                 if (target >= 135) break;
                 const int nb = clockwise_vertices(f, v, cb);
                 if (is_inside_boundary(f, pv, cand, cb, nb, nxt, prv)) { nw = cand; break; }
@@ -884,9 +877,9 @@ k_smooth_front(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int32
         } else {
             // inner_vertex(vertex, 45), M:865-880 (A = vertex.x - m.x with a generated vertex: a NumPy divisor)
             const P2 m = mkp((pn.x + pp.x) / 2, (pn.y + pp.y) / 2);
-            const double d = dist(m, pp) * tab[kFtTan45];
+            const double d = distf(f, m, pp) * tab[kFtTan45];
             const double A = pv.x - m.x, B = pv.y - m.y;
-            const double qq = py_div(f, d * d, A * A + B * B, true);
+            const double qq = py_div(f, sq(f, d), sq(f, A) + sq(f, B), true);
             const double s = py_sqrt(f, qq);
             if (f.raised) break;
             const double ix = m.x + s * A, iy = m.y + s * B;
@@ -908,6 +901,15 @@ k_smooth_front(DevState S, int ring_cap, const uint8_t *__restrict__ mask, int32
             const double2 c = coord[u];
             vnew[u - n0] = c;
             rxy[i] = c;
+        }
+    }
+    // not_valid_points (the move() API) holds the Vertex objects themselves: a listed front vertex that moved is tested
+    // (is_vertex_inside_list, M:428-433) at its new position from now on
+    if (nv_xy) {
+        const int n_nv = uniform_i32(nv_count[env]);
+        for (int k = lane; k < n_nv; k += 64) {
+            const int g = nv_gid[(size_t)env * ring_cap + k];
+            if (g & kNewBit) nv_xy[(size_t)env * ring_cap + k] = coord[n0 + (g & ~kNewBit)];
         }
     }
     if (lane == 0) code_out[env] = f.raised == 2 ? kSmoothNonFinite : (f.raised ? kSmoothRaises : 0);
@@ -945,7 +947,7 @@ struct alignas(32) Reselect {
 template <int kMode>
 __global__ void __launch_bounds__(64)
 k_rebuild_candidates(DevState S, int cap, const uint8_t *__restrict__ mask, const int32_t *__restrict__ sweeps,
-                     Reselect *__restrict__ pend, float *__restrict__ pend_obs, float *__restrict__ obs_out)
+                     Reselect *__restrict__ pend, float *__restrict__ pend_obs, float *__restrict__ obs_out, const LibmRef lr)
 {
     extern __shared__ double2 smem[];
     const int env = blockIdx.x;
@@ -972,7 +974,7 @@ k_rebuild_candidates(DevState S, int cap, const uint8_t *__restrict__ mask, cons
     BqArgs bq;
     bq.skip = false;
     bq.mode = 0; bq.a = 0; bq.b = 0; bq.ang0 = 0; bq.ang1 = 0; bq.q_ang0 = 0; bq.q_ang2 = 0; bq.half01 = 0; bq.half23 = 0;
-    find_next_state(c, S, bq, kMode == 2);
+    find_next_state(c, S, bq, kMode == 2, nullptr, 0, lr);
     if (kMode == 0) {
         if (c.lane < kObsDim) pend_obs[(size_t)env * kObsDim + c.lane] = c.obs;
         if (c.lane == 0) {

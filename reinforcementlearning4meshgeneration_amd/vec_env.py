@@ -56,6 +56,20 @@ class Box:
         return f"Box({self.low}, {self.high}, {self.shape}, {self.dtype})"
 
 
+def smoothing_log_capacity(ring_len: int, want: int = 4096) -> int:
+    """Largest log_capacity <= want whose per-env smoothing graph still fits one CU's 160 KB of LDS
+    (csrc/meshenv_smooth.h: smooth_lds_bytes = 16 B per ring slot + 60 B per logged vertex + 64, front smoother
+    smooth_front_lds_bytes = 49 B per (ring slot + logged vertex) + 2 B per ring slot + 128, smooth_final_lds_bytes = 51 B per
+    (ring slot + logged vertex) + 2 B per ring slot + 64; ring stride = ring length rounded up to 16).
+    tests/test_host_cpu.py checks these formulas against the header."""
+    cap = (int(ring_len) + 15) // 16 * 16
+    lds = 160 * 1024
+    by_interior = (lds - 64 - 16 * cap) // 60
+    by_front = (lds - 128 - 2 * cap) // 49 - cap
+    by_final = (lds - 64 - 2 * cap) // 51 - cap
+    return int(max(16, min(want, by_interior, by_front, by_final, 65535 - cap)))
+
+
 def make_spaces():
     """(observation_space, action_space) with the reference's bounds; real gymnasium/gym Boxes if available."""
     box = None
@@ -271,6 +285,12 @@ class MeshVecEnv:
         self._check(rc, "meshenv_move")
         return self.obs, self.done, self.complete, self.move_code
 
+    @property
+    def libm_exact(self) -> int:
+        """meshenv_libm_exact: 1 = the smoothing kernels square like the running libm's pow(x, 2.0) (validated), 0 = they use
+        x * x (another libm, or MESHENV_LIBM_EXACT=0), -1 = no smoothing call yet."""
+        return int(self._L.meshenv_libm_exact(self._handle))
+
     def smooth_pave(self, mask=None, iteration: int = 400, interior: bool = True, static: bool = False,
                     which: str = "current"):
         """MeshGeneration.smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=iteration, interior=interior)
@@ -462,6 +482,11 @@ class MeshVecEnv:
         rc = self._L.meshenv_get_elements(self._handle, int(env), quads.ctypes.data, cap_e, vxy.ctypes.data, cap_v,
                                           C.byref(ne), C.byref(nv))
         self._check(rc, "meshenv_get_elements")
+        if ne.value >= cap_e and int(self.status().cpu()[int(env)]) & _capi.ST_LOG_OVERFLOW:
+            import warnings   # the log holds the first log_capacity entries only
+            warnings.warn(f"env {env}: the episode outgrew log_capacity = {self.log_capacity}: the mesh returned (and any "
+                          "export, quality report or smoothing of it) is truncated -- create the environment with a larger "
+                          "log_capacity", RuntimeWarning, stacklevel=2)
         return quads[:4 * ne.value].reshape(-1, 4).copy(), vxy[:2 * nv.value].reshape(-1, 2).copy()
 
     def get_last_episode(self, env: int):

@@ -20,8 +20,11 @@ def test_single_env_legacy_and_gymnasium_api_follow_the_reference_trace():
     pts = [tuple(p) for p in tr["domain_xy"]]
     legacy = BoudaryEnv(pts)
     gym5 = BoudaryEnv(pts, api="gymnasium")
+    o_static = legacy.reset(True)            # rl/boundary_env.py:67: reset(static=False) takes the flag positionally
+    assert o_static[1] == 0.0 and np.array_equal(np.delete(o_static, 1), np.delete(tr["reset_obs"], 1))
     o1 = legacy.reset()
     o2, info = gym5.reset(seed=3)
+    hist = {-1: [], 0: [], 1: []}            # what rl/boundary_env.py:229 appends: reward of each accepted element, per rule
     assert isinstance(o1, np.ndarray) and o1.dtype == np.float32 and o1.shape == (18,)
     assert np.array_equal(o1, tr["reset_obs"]) and np.array_equal(o2, tr["reset_obs"]) and info == {}
     assert legacy.observation_space.shape == (18,) and legacy.action_space.shape == (3,)
@@ -38,9 +41,15 @@ def test_single_env_legacy_and_gymnasium_api_follow_the_reference_trace():
         else:
             assert np.abs(obs.astype(np.float64) - tr["obs"][t]).max() <= 1e-5 and np.array_equal(obs, obs5)
         assert len(legacy.generated_meshes) == tr["n_elem"][t]
+        if tr["valid"][t]:
+            rule = -1 if a[0] <= -0.5 else (1 if a[0] >= 0.5 else 0)
+            hist[rule].append(tr["reward"][t] - (10 if done and info["is_complete"] else 0))
         if done:
             legacy.reset()
             gym5.reset()
+    assert sum(len(v) for v in hist.values()) > 20 and all(len(hist[k]) == len(legacy.history_info[k]) for k in hist)
+    for k in hist:                            # history_info survives reset(), like the reference's attribute
+        assert np.abs(np.array(hist[k]) - np.array(legacy.history_info[k], np.float64)).max(initial=0.0) <= 1e-5
     legacy.close()
     gym5.close()
 

@@ -256,6 +256,10 @@ def test_device_front_smoother_replays_reference_records(torch_cuda, name):
     worst, front_moves = replay_front(tr, impl, obs_tol=1e-5, vertex_tol=1e-10, key_tol=1e-9)
     print(name, "largest vertex deviation", worst, "front vertex moves", front_moves)
     assert front_moves > 0
+    # tan / cos come from the host libm's table and `** 2` is the host libm's pow(x, 2.0) restated (csrc/meshenv_libm.h,
+    # validated against the running libm): the vertex tables are the reference's bit for bit, not within a tolerance
+    assert impl.env.libm_exact == 1, "this libm's pow differs from the restated one (regenerate csrc/meshenv_libm_tables.h)"
+    assert worst == 0.0, worst
     impl.env.close()
 
 
@@ -303,7 +307,7 @@ def test_full_size_65536_envs_smooth_pave_with_front_smoother_sampled_oracle_sha
         assert np.array_equal(q, q_ref)
         worst = max(worst, float(np.abs(v - v_ref).max()))
         assert np.array_equal(v[:len(dom)], np.asarray(dom, np.float64))      # the domain ring never moves
-    assert worst <= 1e-10, worst
+    assert worst == 0.0 if env.libm_exact == 1 else worst <= 1e-10, worst
     sweeps2, _ = env.smooth_pave(iteration=400, interior=True)
     assert float(sweeps2.float().mean()) <= float(sweeps.mean())
     steps(8)                               # the smoothed states are the states that are stepped on

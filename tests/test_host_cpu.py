@@ -161,3 +161,25 @@ def test_every_hip_entry_point_runs_on_the_handles_device_and_restores_the_calle
         assert re.search(r"MESHENV_ON_DEVICE\(|DeviceGuard\s+guard\(", f), f"{name.group(1)} has no device guard"
         checked += 1
     assert checked >= 12
+
+
+def test_default_log_capacity_follows_the_smoothers_lds_formulas():
+    """BoudaryEnv sizes its element log so that smooth() / smooth_pave() stay usable (vec_env.smoothing_log_capacity); the
+    byte counts it assumes are the ones csrc/meshenv_smooth.h computes."""
+    from reinforcementlearning4meshgeneration_amd.vec_env import smoothing_log_capacity
+    src = open(os.path.join(ROOT, "reinforcementlearning4meshgeneration_amd", "csrc", "meshenv_smooth.h")).read()
+    assert "constexpr int kSmoothMaxDeg = 16;" in src
+    assert "return (size_t)(ring_cap + log_cap) * sizeof(double2) + (size_t)log_cap * (8 + kSmoothMaxDeg * 2 + 2 + 2) + 64;" in src
+    assert "return V * sizeof(double2) + V * kSmoothMaxDeg * 2 + (size_t)ring_cap * 2 + 2 * kSmoothMaxDeg * 2 + V + 64;" in src
+    assert "return V * sizeof(double2) + V * kSmoothMaxDeg * 2 + (size_t)ring_cap * 2 + V * 3 + 64;" in src
+
+    def interior(c, l): return (c + l) * 16 + l * (8 + 32 + 2 + 2) + 64
+    def front(c, l): return (c + l) * 16 + (c + l) * 32 + c * 2 + 64 + (c + l) + 64
+    def final(c, l): return (c + l) * 16 + (c + l) * 32 + c * 2 + (c + l) * 3 + 64
+    for ring in (6, 30, 120, 196, 272, 640, 1500):
+        cap = (ring + 15) // 16 * 16
+        lc = smoothing_log_capacity(ring)
+        assert max(interior(cap, lc), front(cap, lc), final(cap, lc)) <= 160 * 1024 and cap + lc <= 65535
+        if lc < 4096:   # tight: one more logged vertex would not fit
+            assert max(interior(cap, lc + 1), front(cap, lc + 1), final(cap, lc + 1)) > 160 * 1024
+    assert smoothing_log_capacity(30) >= 2400 and smoothing_log_capacity(272) >= 2000
