@@ -31,7 +31,16 @@ struct GenParams {
     double ctr_x, ctr_y, ave_radius, irregularity, spikeyness;  // generatePolygon arguments (250, 250, 100, 0.55, 0.7)
     double edge;                                                // densify target (0.45)
     int fixed_verts;                                            // > 0: numVerts for every ring; 0: randint(8, 64) per stream
+    // ---- density mode (meshenv_create_random_density): the reference's own graded subdivision instead of the uniform split
+    int density_mode;                    // 0: domains.densify (uniform); 1: Density.calculate_density, ui/tk-ui.py:252-276
+    double base_length, density;         // spacing in pixels, per-vertex density (the same for every generated vertex)
+    const unsigned long long *seeds;     // [n] explicit seed per ring, or nullptr: seed0 + k
+    const double2 *dir_tab;              // (cos, sin)(clockwise_angle) by pixel offset, [(2 R + 1)^2], host libm
+    int dir_r;                           // R
+    unsigned char *raises;               // [n] nullable: 1 where calculate_density raises ZeroDivisionError
 };
+
+constexpr int kDensMaxPts = 2048;    // points of one densified ring (LDS staging of the density mode)
 
 // LDS of one generating wavefront
 struct GenScratch {
@@ -42,7 +51,172 @@ struct GenScratch {
     int px[kGenMaxVerts], py[kGenMaxVerts];
     double2 ring[kGenMaxVerts];  // deduplicated polygon / 100, clockwise
     int pieces[kGenMaxVerts], off[kGenMaxVerts + 1];
+    int qx[kGenMaxVerts], qy[kGenMaxVerts];   // the same polygon in pixels, generated order (density mode)
 };
+
+// ------------------------------------------------------------------------------------------ Density.calculate_density
+//
+// ui/tk-ui.py:252-276 as domains.calculate_density restates it, followed by the orientation rule of the UI's save
+// (:84-101, 169-176) and read_polygon's division by 100 (general/polygon.py:110-117) -- domains.density_domain, the
+// reference's whole route from a drawn / generated pixel polygon to a domain ring.  One wavefront per polygon:
+//   * the dict keyed by coordinates: a repeated pixel keeps its first position (and its LAST density);
+//   * edge i runs from vertex i - 1 to vertex i (edge 0 from the last vertex): A = density(prev) * base_length,
+//     B = density(i) * base_length, L = its length, x = round((2 L - A - B) / (A + B)) (Python round: half to even),
+//     e = (B - A) / x -- ZeroDivisionError for x == 0, reported per ring -- offsets A (j + 1) + e (j^2 + j) / 2 for j < x,
+//     then L; points prev + offset * (cos, sin)(clockwise_angle(prev, i));
+//   * the last edge drops its middle point (index len // 2) when the total would be odd;
+//   * reversed unless the shoelace sum (builtin sum: left to right from 0) is negative; / 100.
+// cos / sin of the edge direction are the one non-IEEE step; pixel polygons have INTEGER offsets, so the host evaluates
+// clockwise_angle / math.cos / math.sin with its own libm -- the reference's -- once per offset (dir_tab, meshenv_hip.hip:
+// fill_direction_table) or once per edge (edge_dir, explicit polygons): the device result is the reference's bit for bit.
+struct DensScratch {
+    int px[kGenMaxVerts * 4], py[kGenMaxVerts * 4];   // deduplicated polygon, pixels (explicit polygons: up to 256 vertices)
+    double dens[kGenMaxVerts * 4];
+    double2 dir[kGenMaxVerts * 4];                     // (cos, sin) of edge i
+    double A[kGenMaxVerts * 4], E[kGenMaxVerts * 4], L[kGenMaxVerts * 4];
+    int X[kGenMaxVerts * 4], cnt[kGenMaxVerts * 4], off[kGenMaxVerts * 4 + 1];
+    double2 res[kDensMaxPts];
+};
+constexpr int kDensMaxVerts = kGenMaxVerts * 4;
+
+// m polygon vertices are in d->px / py / dens (dict-deduplicated, m >= 3) and their edge directions in d->dir.
+// Returns the number of ring points (kWrite: written to out_xy), 0 with *status = 1 where the reference raises
+// ZeroDivisionError, 0 with *status = 2 when the ring does not fit kDensMaxPts.
+template <bool kWrite>
+__device__ __forceinline__ int density_ring(DensScratch *d, int m, double base_length, int lane, double2 *out_xy, int *status)
+{
+    bool zero = false;
+    for (int i = lane; i < m; i += 64) {
+        const int ip = i == 0 ? m - 1 : i - 1;
+        const double B = d->dens[i] * base_length, A = d->dens[ip] * base_length;
+        const long long dx = (long long)d->px[ip] - d->px[i], dy = (long long)d->py[ip] - d->py[i];
+        const double L = sqrt((double)(dx * dx + dy * dy));          // math.sqrt of an exact int
+        const double xr = rint((2 * L - A - B) / (A + B));            // round(): to nearest, ties to even
+        const int x = (int)xr;
+        zero = zero || x == 0;
+        d->A[i] = A; d->L[i] = L; d->X[i] = x;
+        d->E[i] = x != 0 ? (B - A) / xr : 0.0;
+        d->cnt[i] = (x > 0 ? x : 0) + 1;                               // range(x) offsets, then L
+    }
+    if (__ballot(zero) != 0ULL) {
+        *status = 1;
+        return 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int total = 0;
+    if (lane == 0) {
+        int o = 0;
+        for (int i = 0; i < m; i++) { d->off[i] = o; o += d->cnt[i]; }
+        d->off[m] = o;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    total = d->off[m];
+    // M:270-272: on the last edge, (len(res_points) + len(interpolations)) odd -> pop(int(len(interpolations) / 2))
+    const int last_len = d->cnt[m - 1];
+    const bool pop = (total & 1) != 0;
+    const int pop_at = last_len / 2;
+    const int n_out = total - (pop ? 1 : 0);
+    if (n_out > kDensMaxPts) {
+        *status = 2;
+        return 0;
+    }
+    if (!kWrite) return n_out;
+    for (int e = 0; e < m; e++) {
+        const int ep = e == 0 ? m - 1 : e - 1;
+        const double A = d->A[e], E = d->E[e], L = d->L[e];
+        const int x = d->X[e], c = d->cnt[e], o = d->off[e];
+        const double2 cs = d->dir[e];
+        const double bx = (double)d->px[ep], by = (double)d->py[ep];
+        for (int j = lane; j < c; j += 64) {
+            // A * (j + 1) + e * (j ** 2 + j) / 2  -- float * int, float * int, / 2, +
+            const double t = j < x ? A * (double)(j + 1) + (E * (double)(j * j + j)) / 2 : L;
+            int slot = o + j;
+            bool skip = false;
+            if (pop && e == m - 1) {
+                skip = j == pop_at;
+                slot -= j > pop_at ? 1 : 0;
+            }
+            if (!skip) d->res[slot] = make_double2(bx + t * cs.x, by + t * cs.y);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // check_clockwise: sum([p[i-1].x * p[i].y - p[i-1].y * p[i].x]) < 0, builtin sum from int 0, left to right
+    double s = 0.0;
+    if (lane == 0) {
+        for (int i = 0; i < n_out; i++) {
+            const double2 p = d->res[i], q = d->res[i == 0 ? n_out - 1 : i - 1];
+            s = s + (q.x * p.y - q.y * p.x);
+        }
+    }
+    const bool reversed = !(uniform_f64(s) < 0.0);
+    for (int i = lane; i < n_out; i += 64) {
+        const double2 p = d->res[reversed ? n_out - 1 - i : i];
+        out_xy[i] = make_double2(p.x / 100, p.y / 100);
+    }
+    return n_out;
+}
+
+// dict keyed by coordinates over n pixel vertices (px, py, dens in `src`): first position, last density; compacted into d.
+__device__ __forceinline__ int density_dedupe(DensScratch *d, const int *sx, const int *sy, const double *sd, double dens_all,
+                                              int n, int lane)
+{
+    int m = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        bool first = false;
+        double dv = dens_all;
+        if (i < n) {
+            first = true;
+            for (int j = 0; j < i; j++) first = first && !(sx[j] == sx[i] && sy[j] == sy[i]);
+            if (sd) {
+                dv = sd[i];
+                for (int j = i + 1; j < n; j++) dv = (sx[j] == sx[i] && sy[j] == sy[i]) ? sd[j] : dv;   // the last density wins
+            }
+        }
+        const unsigned long long mk = __ballot(first);
+        if (first) {
+            const int r = m + __popcll(mk & ((1ULL << lane) - 1ULL));
+            d->px[r] = sx[i]; d->py[r] = sy[i]; d->dens[r] = dv;
+        }
+        m += __popcll(mk);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return m;
+}
+
+// Explicit pixel polygons (meshenv_density_rings): polygon k = vertices [poly_off[k], poly_off[k + 1]) of px / py / dens,
+// edge directions per input vertex pair from the host (edge_dir[poly_off[k] * ... ] is indexed by DEDUPLICATED vertex, see
+// the host side).  count[k] = ring length, status[k] = 0 ok / 1 raises / 2 too long / 3 fewer than 3 distinct vertices.
+template <bool kWrite>
+__global__ void __launch_bounds__(64)
+k_density_rings(int n, const int32_t *poly_off, const int32_t *pxy, const double *dens, const double2 *edge_dir, double base_length,
+                const int32_t *out_off, double2 *out_xy, int32_t *count, unsigned char *status)
+{
+    __shared__ DensScratch d;
+    __shared__ int sx[kDensMaxVerts], sy[kDensMaxVerts];
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const int o = poly_off[k], nv = poly_off[k + 1] - o;
+    for (int i = lane; i < nv; i += 64) { sx[i] = pxy[2 * (o + i)]; sy[i] = pxy[2 * (o + i) + 1]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int m = density_dedupe(&d, sx, sy, dens ? dens + o : nullptr, 1.0, nv, lane);
+    int st = 0, c = 0;
+    if (m < 3) st = 3;
+    else {
+        for (int i = lane; i < m; i += 64) d.dir[i] = edge_dir[o + i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        c = density_ring<kWrite>(&d, m, base_length, lane, kWrite ? out_xy + out_off[k] : nullptr, &st);
+    }
+    if (lane == 0) {
+        if (!kWrite) count[k] = c;
+        status[k] = (unsigned char)st;
+    }
+}
 
 // init_by_array + one twist + tempering: out[0..623] are the stream's first 624 outputs (lane 0 runs the two serial
 // recurrences, the tempering is per element)
@@ -99,7 +273,7 @@ __device__ __forceinline__ double clipd(double x, double lo, double hi) { return
 // Returns the vertex count, 0 on failure (fail bit set in *err: the stream's first 624 outputs did not suffice).
 template <bool kWrite>
 __device__ __forceinline__ int gen_ring(GenScratch *g, const GenParams &P, unsigned long long seed, int lane, double2 *out_xy,
-                                        int *err)
+                                        int *err, DensScratch *dsc = nullptr, int ring_index = 0)
 {
     mt_seed_and_fill(g, seed, lane);
     int pos = 0;
@@ -165,7 +339,12 @@ __device__ __forceinline__ int gen_ring(GenScratch *g, const GenParams &P, unsig
             keep = keep && lane != last;
             cnt -= 1;
         }
-        if (keep) g->ring[__popcll(m & ((1ULL << lane) - 1ULL))] = make_double2(g->px[lane] / 100.0, g->py[lane] / 100.0);
+        if (keep) {
+            const int r = __popcll(m & ((1ULL << lane) - 1ULL));
+            g->ring[r] = make_double2(g->px[lane] / 100.0, g->py[lane] / 100.0);
+            g->qx[r] = g->px[lane];
+            g->qy[r] = g->py[lane];
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // random_polygon_px() draws another polygon from the same stream when fewer than 5 distinct vertices remain (with
@@ -176,6 +355,33 @@ __device__ __forceinline__ int gen_ring(GenScratch *g, const GenParams &P, unsig
             return 0;
         }
         n_ring = cnt;
+    }
+    if (dsc != nullptr) {
+        // ---- density mode: calculate_density on the pixel polygon (generated order), then orientation and / 100
+        const int m = density_dedupe(dsc, g->qx, g->qy, nullptr, P.density, n_ring, lane);
+        int st = 0, c = 0;
+        if (m < 3) st = 3;
+        else {
+            const int R = P.dir_r, W = 2 * R + 1;
+            bool out_of_table = false;
+            for (int i = lane; i < m; i += 64) {
+                const int ip = i == 0 ? m - 1 : i - 1;
+                const int dx = dsc->px[i] - dsc->px[ip], dy = dsc->py[i] - dsc->py[ip];   // clockwise_angle(prev, i)
+                const bool in = dx >= -R && dx <= R && dy >= -R && dy <= R;
+                out_of_table = out_of_table || !in;
+                dsc->dir[i] = in ? P.dir_tab[(size_t)(dx + R) * W + (dy + R)] : make_double2(1.0, 0.0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (__ballot(out_of_table) != 0ULL) st = 2;
+            else c = density_ring<kWrite>(dsc, m, P.base_length, lane, out_xy, &st);
+        }
+        if (lane == 0) {
+            if (st == 1 && P.raises) P.raises[ring_index] = 1;
+            if (st >= 2) atomicOr(err, 4);
+            if (st == 1 && !P.raises) atomicOr(err, 8);
+        }
+        return c;
     }
     // ---- orientation: sum(x[i-1] * y[i] - y[i-1] * x[i]) < 0 is clockwise, else the list is reversed
     bool reversed = false;
@@ -227,12 +433,17 @@ __device__ __forceinline__ int gen_ring(GenScratch *g, const GenParams &P, unsig
     return total;
 }
 
+__device__ __forceinline__ unsigned long long ring_seed(const GenParams &P, int k)
+{
+    return P.seeds ? P.seeds[k] : P.seed0 + (unsigned long long)k;
+}
+
 // pass 1: ring lengths
 __global__ void __launch_bounds__(64) k_gen_count(GenParams P, int n, int32_t *count, int *err)
 {
     __shared__ GenScratch g;
     const int k = blockIdx.x, lane = threadIdx.x;
-    const int c = gen_ring<false>(&g, P, P.seed0 + (unsigned long long)k, lane, nullptr, err);
+    const int c = gen_ring<false>(&g, P, ring_seed(P, k), lane, nullptr, err);
     if (lane == 0) count[k] = c;
 }
 
@@ -241,7 +452,26 @@ __global__ void __launch_bounds__(64) k_gen_rings(GenParams P, int n, const int3
 {
     __shared__ GenScratch g;
     const int k = blockIdx.x, lane = threadIdx.x;
-    const int c = gen_ring<true>(&g, P, P.seed0 + (unsigned long long)k, lane, dom_xy + offsets[k], err);
+    const int c = gen_ring<true>(&g, P, ring_seed(P, k), lane, dom_xy + offsets[k], err);
+    if (lane == 0 && c != offsets[k + 1] - offsets[k]) atomicOr(err, 2);
+}
+
+// the same two passes in density mode (their own kernels: the 80 KB of density staging stay out of the uniform mode's LDS)
+__global__ void __launch_bounds__(64) k_gen_count_density(GenParams P, int n, int32_t *count, int *err)
+{
+    __shared__ GenScratch g;
+    __shared__ DensScratch d;
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const int c = gen_ring<false>(&g, P, ring_seed(P, k), lane, nullptr, err, &d, k);
+    if (lane == 0) count[k] = c;
+}
+
+__global__ void __launch_bounds__(64) k_gen_rings_density(GenParams P, int n, const int32_t *offsets, double2 *dom_xy, int *err)
+{
+    __shared__ GenScratch g;
+    __shared__ DensScratch d;
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const int c = gen_ring<true>(&g, P, ring_seed(P, k), lane, dom_xy + offsets[k], err, &d, k);
     if (lane == 0 && c != offsets[k + 1] - offsets[k]) atomicOr(err, 2);
 }
 

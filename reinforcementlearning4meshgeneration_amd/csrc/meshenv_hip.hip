@@ -371,7 +371,10 @@ static int create_impl(int device, int n_domains, const int32_t *dom_offsets_hos
         CREATE_TRY(dev_alloc(h, &d_err, (size_t)1));
         CREATE_HIP(hipMemcpy(d_off, dom_offsets_host, sizeof(int32_t) * ((size_t)n_domains + 1), hipMemcpyHostToDevice));
         CREATE_HIP(hipMemset(d_err, 0, sizeof(int)));
-        hipLaunchKernelGGL(k_gen_rings, dim3(n_domains), dim3(64), 0, h->stream, *gen, n_domains, (const int32_t *)d_off, d_dom_xy, d_err);
+        if (gen->density_mode)
+            hipLaunchKernelGGL(k_gen_rings_density, dim3(n_domains), dim3(64), 0, h->stream, *gen, n_domains, (const int32_t *)d_off, d_dom_xy, d_err);
+        else
+            hipLaunchKernelGGL(k_gen_rings, dim3(n_domains), dim3(64), 0, h->stream, *gen, n_domains, (const int32_t *)d_off, d_dom_xy, d_err);
         CREATE_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_dom_consts, dim3(n_domains), dim3(64), sizeof(double2) * (size_t)max_ring, h->stream, n_domains,
                            (const int32_t *)d_off, (const double2 *)d_dom_xy, S.dom);
@@ -412,6 +415,112 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
                        stream, nullptr, out);
 }
 
+// clockwise_angle(a, b) of ui/tk-ui.py:185-192 and its cosine / sine, for the integer pixel offset (dx, dy) = b - a: the
+// host libm's values -- the reference's -- in the reference's expression order (domains.clockwise_angle).
+static void edge_direction(int dx, int dy, double *cs)
+{
+    volatile double ny = -(double)dy, x = (double)dx;        // volatile: the calls must reach the running libm
+    const double theta = -std::atan2(ny, x);
+    volatile double angle = std::copysign(1.0, theta) >= 0 ? theta : 2 * 3.141592653589793 + theta;
+    cs[0] = std::cos(angle);
+    cs[1] = std::sin(angle);
+}
+
+// shared by meshenv_create_random (uniform split) and meshenv_create_random_density (calculate_density)
+static int create_random_impl(const char *fn, int device, int n_envs, GenParams gp, const uint64_t *seeds_host,
+                              const MeshEnvParams *params, void *stream, MeshEnv **out, uint8_t *raises_host)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = std::string(fn) + ": no HIP device available (this library has no CPU fallback)";
+        return MESHENV_E_HIP;
+    }
+    if (device < 0 || device >= ndev) return fail_arg(nullptr, "meshenv_create_random: device index out of range");
+    // pass 1: the ring lengths (the domain table and the ring stride are sized from them)
+    std::vector<int32_t> offs((size_t)n_envs + 1, 0), env_dom((size_t)n_envs);
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) { g_create_error = std::string(fn) + ": hipSetDevice failed"; return MESHENV_E_HIP; }
+    int32_t *d_cnt = nullptr;
+    int *d_err = nullptr;
+    unsigned long long *d_seeds = nullptr;
+    double2 *d_tab = nullptr;
+    unsigned char *d_raises = nullptr;
+    auto cleanup = [&]() {
+        if (d_cnt) (void)hipFree(d_cnt);
+        if (d_err) (void)hipFree(d_err);
+        if (d_seeds) (void)hipFree(d_seeds);
+        if (d_tab) (void)hipFree(d_tab);
+        if (d_raises) (void)hipFree(d_raises);
+    };
+    bool ok = hipMalloc((void **)&d_cnt, sizeof(int32_t) * (size_t)n_envs) == hipSuccess &&
+              hipMalloc((void **)&d_err, sizeof(int)) == hipSuccess && hipMemset(d_err, 0, sizeof(int)) == hipSuccess;
+    if (ok && seeds_host) {
+        ok = hipMalloc((void **)&d_seeds, sizeof(unsigned long long) * (size_t)n_envs) == hipSuccess &&
+             hipMemcpy(d_seeds, seeds_host, sizeof(unsigned long long) * (size_t)n_envs, hipMemcpyHostToDevice) == hipSuccess;
+        gp.seeds = d_seeds;
+    }
+    if (ok && gp.density_mode) {
+        // pixel coordinates lie in ctr -+ 2 aveRadius (radii are clipped to [0, 2 aveRadius]): offsets within 4 aveRadius + 1
+        const int R = (int)std::ceil(4 * gp.ave_radius) + 1, W = 2 * R + 1;
+        std::vector<double> tab((size_t)W * W * 2);
+        for (int dx = -R; dx <= R; dx++)
+            for (int dy = -R; dy <= R; dy++) edge_direction(dx, dy, &tab[((size_t)(dx + R) * W + (dy + R)) * 2]);
+        ok = hipMalloc((void **)&d_tab, sizeof(double2) * (size_t)W * W) == hipSuccess &&
+             hipMemcpy(d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMalloc((void **)&d_raises, (size_t)n_envs) == hipSuccess && hipMemset(d_raises, 0, (size_t)n_envs) == hipSuccess;
+        gp.dir_tab = d_tab;
+        gp.dir_r = R;
+        gp.raises = d_raises;
+    }
+    int err = 0;
+    if (ok) {
+        if (gp.density_mode) hipLaunchKernelGGL(k_gen_count_density, dim3(n_envs), dim3(64), 0, (hipStream_t)stream, gp, n_envs, d_cnt, d_err);
+        else hipLaunchKernelGGL(k_gen_count, dim3(n_envs), dim3(64), 0, (hipStream_t)stream, gp, n_envs, d_cnt, d_err);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
+             hipMemcpy(offs.data() + 1, d_cnt, sizeof(int32_t) * (size_t)n_envs, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    int n_raise = 0;
+    if (ok && gp.density_mode) {
+        std::vector<uint8_t> rz((size_t)n_envs);
+        ok = hipMemcpy(rz.data(), d_raises, (size_t)n_envs, hipMemcpyDeviceToHost) == hipSuccess;
+        for (int k = 0; k < n_envs; k++) n_raise += rz[(size_t)k] ? 1 : 0;
+        if (raises_host) std::memcpy(raises_host, rz.data(), (size_t)n_envs);
+    }
+    if (!ok) { cleanup(); g_create_error = std::string(fn) + ": the ring-length pass failed (HIP error)"; return MESHENV_E_HIP; }
+    if (err) {
+        cleanup();
+        g_create_error = std::string(fn) + ": a ring could not be generated on the device (fewer than 5 distinct pixels, or a densified ring beyond 2048 points)";
+        return MESHENV_E_STATE;
+    }
+    if (n_raise) {
+        cleanup();
+        g_create_error = std::string(fn) + ": calculate_density raises ZeroDivisionError for " + std::to_string(n_raise) + " of " +
+                         std::to_string(n_envs) + " polygons (an edge of 0.5 - 1.5 spacings, ui/tk-ui.py:263-264): see raises_host and pass seeds without them";
+        return MESHENV_E_STATE;
+    }
+    if (!out) { cleanup(); return MESHENV_OK; }   // probe only
+    for (int k = 0; k < n_envs; k++) {
+        if (offs[(size_t)k + 1] < 4) { cleanup(); g_create_error = std::string(fn) + ": empty ring"; return MESHENV_E_STATE; }
+        offs[(size_t)k + 1] += offs[(size_t)k];
+        env_dom[(size_t)k] = k;
+    }
+    gp.raises = nullptr;   // pass 2 runs on rings that do not raise
+    const int rc = create_impl(device, n_envs, offs.data(), nullptr, nullptr, n_envs, env_dom.data(), params, stream, &gp, out);
+    cleanup();
+    return rc;
+}
+
+static GenParams default_gen_params(uint64_t seed0, int num_verts)
+{
+    GenParams gp;
+    std::memset(&gp, 0, sizeof(gp));
+    gp.seed0 = seed0;
+    gp.ctr_x = 250; gp.ctr_y = 250; gp.ave_radius = 100; gp.irregularity = 0.55; gp.spikeyness = 0.7;  // GenerateRandomPolygon.py:63
+    gp.fixed_verts = num_verts;
+    return gp;
+}
+
 int meshenv_create_random(int device, int n_envs, uint64_t seed0, int num_verts, double edge, const MeshEnvParams *params,
                           void *stream, MeshEnv **out)
 {
@@ -419,44 +528,104 @@ int meshenv_create_random(int device, int n_envs, uint64_t seed0, int num_verts,
     *out = nullptr;
     if (n_envs <= 0 || !(edge > 0.0) || num_verts < 0 || (num_verts > 0 && (num_verts < 5 || num_verts > kGenMaxVerts)))
         return fail_arg(nullptr, "meshenv_create_random: n_envs > 0, edge > 0 and num_verts in {0, 5..64} are required");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        g_create_error = "meshenv_create_random: no HIP device available (this library has no CPU fallback)";
-        return MESHENV_E_HIP;
-    }
-    if (device < 0 || device >= ndev) return fail_arg(nullptr, "meshenv_create_random: device index out of range");
-    GenParams gp;
-    gp.seed0 = seed0;
-    gp.ctr_x = 250; gp.ctr_y = 250; gp.ave_radius = 100; gp.irregularity = 0.55; gp.spikeyness = 0.7;  // GenerateRandomPolygon.py:63
+    GenParams gp = default_gen_params(seed0, num_verts);
     gp.edge = edge;
-    gp.fixed_verts = num_verts;
-    // pass 1: the ring lengths (the domain table and the ring stride are sized from them)
-    std::vector<int32_t> offs((size_t)n_envs + 1, 0), env_dom((size_t)n_envs);
-    {
-        DeviceGuard guard(device);
-        if (guard.err != hipSuccess) { g_create_error = "meshenv_create_random: hipSetDevice failed"; return MESHENV_E_HIP; }
-        int32_t *d_cnt = nullptr;
-        int *d_err = nullptr;
-        bool ok = hipMalloc((void **)&d_cnt, sizeof(int32_t) * (size_t)n_envs) == hipSuccess &&
-                  hipMalloc((void **)&d_err, sizeof(int)) == hipSuccess && hipMemset(d_err, 0, sizeof(int)) == hipSuccess;
-        int err = 0;
-        if (ok) {
-            hipLaunchKernelGGL(k_gen_count, dim3(n_envs), dim3(64), 0, (hipStream_t)stream, gp, n_envs, d_cnt, d_err);
-            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
-                 hipMemcpy(offs.data() + 1, d_cnt, sizeof(int32_t) * (size_t)n_envs, hipMemcpyDeviceToHost) == hipSuccess &&
-                 hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    return create_random_impl("meshenv_create_random", device, n_envs, gp, nullptr, params, stream, out, nullptr);
+}
+
+int meshenv_create_random_density(int device, int n_envs, uint64_t seed0, const uint64_t *seeds_host, int num_verts,
+                                  double base_length, double density, const MeshEnvParams *params, void *stream, MeshEnv **out,
+                                  uint8_t *raises_host)
+{
+    if (out) *out = nullptr;
+    if (n_envs <= 0 || !(base_length > 0.0) || !(density > 0.0) || num_verts < 0 ||
+        (num_verts > 0 && (num_verts < 5 || num_verts > kGenMaxVerts)))
+        return fail_arg(nullptr, "meshenv_create_random_density: n_envs > 0, base_length > 0, density > 0 and num_verts in {0, 5..64} are required");
+    GenParams gp = default_gen_params(seed0, num_verts);
+    gp.density_mode = 1;
+    gp.base_length = base_length;
+    gp.density = density;
+    return create_random_impl("meshenv_create_random_density", device, n_envs, gp, seeds_host, params, stream, out, raises_host);
+}
+
+int meshenv_density_rings(int device, int n_polys, const int32_t *poly_offsets_host, const int32_t *pixels_host,
+                          const double *densities_host, double base_length, int32_t *count_host, uint8_t *status_host,
+                          double *xy_host, int64_t cap_points)
+{
+    if (n_polys <= 0 || !poly_offsets_host || !pixels_host || !count_host || !status_host || !(base_length > 0.0))
+        return MESHENV_E_ARG;
+    const int total_in = poly_offsets_host[n_polys];
+    for (int k = 0; k < n_polys; k++) {
+        const int nv = poly_offsets_host[k + 1] - poly_offsets_host[k];
+        if (nv < 3 || nv > kDensMaxVerts) return MESHENV_E_ARG;
+    }
+    // Edge directions from the host libm.  The device deduplicates repeated pixels (the reference's dict), so the
+    // direction of the edge INTO deduplicated vertex r is computed here for the same deduplicated list.
+    std::vector<double> dir((size_t)total_in * 2, 0.0);
+    for (int k = 0; k < n_polys; k++) {
+        const int o = poly_offsets_host[k], nv = poly_offsets_host[k + 1] - o;
+        std::vector<int> keep;
+        for (int i = 0; i < nv; i++) {
+            bool first = true;
+            for (int j = 0; j < i && first; j++) first = !(pixels_host[2 * (o + j)] == pixels_host[2 * (o + i)] && pixels_host[2 * (o + j) + 1] == pixels_host[2 * (o + i) + 1]);
+            if (first) keep.push_back(i);
         }
-        if (d_cnt) (void)hipFree(d_cnt);
-        if (d_err) (void)hipFree(d_err);
-        if (!ok) { g_create_error = "meshenv_create_random: the ring-length pass failed (HIP error)"; return MESHENV_E_HIP; }
-        if (err) { g_create_error = "meshenv_create_random: a ring could not be generated on the device (fewer than 5 distinct pixels)"; return MESHENV_E_STATE; }
+        const int m = (int)keep.size();
+        for (int r = 0; r < m; r++) {
+            const int i = keep[(size_t)r], ip = keep[(size_t)(r == 0 ? m - 1 : r - 1)];
+            edge_direction(pixels_host[2 * (o + i)] - pixels_host[2 * (o + ip)], pixels_host[2 * (o + i) + 1] - pixels_host[2 * (o + ip) + 1],
+                           &dir[2 * (size_t)(o + r)]);
+        }
     }
-    for (int k = 0; k < n_envs; k++) {
-        if (offs[(size_t)k + 1] < 4) { g_create_error = "meshenv_create_random: empty ring"; return MESHENV_E_STATE; }
-        offs[(size_t)k + 1] += offs[(size_t)k];
-        env_dom[(size_t)k] = k;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return MESHENV_E_HIP;
+    int32_t *d_off = nullptr, *d_px = nullptr, *d_cnt = nullptr, *d_ooff = nullptr;
+    double *d_dens = nullptr;
+    double2 *d_dir = nullptr, *d_out = nullptr;
+    unsigned char *d_st = nullptr;
+    int rc = MESHENV_OK;
+    auto H = [&](hipError_t e) { if (e != hipSuccess && rc == MESHENV_OK) rc = MESHENV_E_HIP; return e == hipSuccess; };
+    H(hipMalloc((void **)&d_off, sizeof(int32_t) * ((size_t)n_polys + 1)));
+    H(hipMalloc((void **)&d_px, sizeof(int32_t) * 2 * (size_t)total_in));
+    H(hipMalloc((void **)&d_cnt, sizeof(int32_t) * (size_t)n_polys));
+    H(hipMalloc((void **)&d_ooff, sizeof(int32_t) * ((size_t)n_polys + 1)));
+    H(hipMalloc((void **)&d_dir, sizeof(double2) * (size_t)total_in));
+    H(hipMalloc((void **)&d_st, (size_t)n_polys));
+    if (densities_host) H(hipMalloc((void **)&d_dens, sizeof(double) * (size_t)total_in));
+    if (rc == MESHENV_OK) {
+        H(hipMemcpy(d_off, poly_offsets_host, sizeof(int32_t) * ((size_t)n_polys + 1), hipMemcpyHostToDevice));
+        H(hipMemcpy(d_px, pixels_host, sizeof(int32_t) * 2 * (size_t)total_in, hipMemcpyHostToDevice));
+        H(hipMemcpy(d_dir, dir.data(), sizeof(double) * dir.size(), hipMemcpyHostToDevice));
+        if (densities_host) H(hipMemcpy(d_dens, densities_host, sizeof(double) * (size_t)total_in, hipMemcpyHostToDevice));
     }
-    return create_impl(device, n_envs, offs.data(), nullptr, nullptr, n_envs, env_dom.data(), params, stream, &gp, out);
+    std::vector<int32_t> ooff((size_t)n_polys + 1, 0);
+    if (rc == MESHENV_OK) {
+        hipLaunchKernelGGL(k_density_rings<false>, dim3(n_polys), dim3(64), 0, nullptr, n_polys, (const int32_t *)d_off, (const int32_t *)d_px,
+                           (const double *)d_dens, (const double2 *)d_dir, base_length, (const int32_t *)nullptr, (double2 *)nullptr, d_cnt, d_st);
+        H(hipGetLastError());
+        H(hipDeviceSynchronize());
+        H(hipMemcpy(count_host, d_cnt, sizeof(int32_t) * (size_t)n_polys, hipMemcpyDeviceToHost));
+        H(hipMemcpy(status_host, d_st, (size_t)n_polys, hipMemcpyDeviceToHost));
+    }
+    if (rc == MESHENV_OK && xy_host) {
+        for (int k = 0; k < n_polys; k++) ooff[(size_t)k + 1] = ooff[(size_t)k] + (status_host[k] == 0 ? count_host[k] : 0);
+        const int64_t total_out = ooff[(size_t)n_polys];
+        if (total_out > cap_points) rc = MESHENV_E_RANGE;
+        else if (total_out > 0) {
+            H(hipMalloc((void **)&d_out, sizeof(double2) * (size_t)total_out));
+            H(hipMemcpy(d_ooff, ooff.data(), sizeof(int32_t) * ((size_t)n_polys + 1), hipMemcpyHostToDevice));
+            if (rc == MESHENV_OK) {
+                hipLaunchKernelGGL(k_density_rings<true>, dim3(n_polys), dim3(64), 0, nullptr, n_polys, (const int32_t *)d_off, (const int32_t *)d_px,
+                                   (const double *)d_dens, (const double2 *)d_dir, base_length, (const int32_t *)d_ooff, d_out, d_cnt, d_st);
+                H(hipGetLastError());
+                H(hipDeviceSynchronize());
+                H(hipMemcpy(xy_host, d_out, sizeof(double2) * (size_t)total_out, hipMemcpyDeviceToHost));
+            }
+        }
+    }
+    for (void *p : {(void *)d_off, (void *)d_px, (void *)d_cnt, (void *)d_ooff, (void *)d_dens, (void *)d_dir, (void *)d_out, (void *)d_st})
+        if (p) (void)hipFree(p);
+    return rc;
 }
 
 int meshenv_get_domain(MeshEnv *h, int domain, double *xy_host, int cap_points, int32_t *n_out, double *consts_host)

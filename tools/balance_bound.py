@@ -24,6 +24,14 @@ valid = (rew != -1.0).cpu().numpy()
 nv = int(valid.sum())
 print(f"{nv} of {n} actions extract an element on the reset ring ({100.0 * nv / n:.1f} %), kernel {env.step_kernel}")
 vi, ii = np.nonzero(valid)[0], np.nonzero(~valid)[0]
+frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0   # e.g. 0.113: the steady-state valid rate of the random policy
+if frac > 0:   # thin the valid actions out to that rate (replace the surplus by copies of invalid actions)
+    keep = int(round(frac * n))
+    drop = vi[keep:]
+    a[torch.from_numpy(drop).cuda()] = a[torch.from_numpy(ii[:len(drop)]).cuda()]
+    valid[drop] = False
+    vi, ii = np.nonzero(valid)[0], np.nonzero(~valid)[0]
+    print(f"thinned to {len(vi)} valid actions ({100.0 * len(vi) / n:.1f} %)")
 
 def layout(kind):
     order = np.empty(n, np.int64)
