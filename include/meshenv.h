@@ -116,6 +116,41 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
 int meshenv_create_random(int device, int n_envs, uint64_t seed0, int num_verts, double edge, const MeshEnvParams *params,
                           void *stream, MeshEnv **out);
 
+/*
+ * The same generator followed by the REFERENCE's densification instead of the uniform split: Density.calculate_density
+ * (ui/tk-ui.py:252-276; arithmetic-progression spacing from density(prev) * base_length to density(k) * base_length on
+ * every edge, Python round half-to-even, one middle point dropped on the last edge for an even total), the UI's
+ * clockwise rule on the result (:84-101, 169-176) and read_polygon's / 100 (general/polygon.py:110-117) -- the route
+ * reinforcementlearning4meshgeneration_amd.domains.density_domain(random_polygon_px(seed), base_length) restates on the
+ * host, bit-identical (tests/test_gpu_domgen.py).  base_length is in PIXELS (45 = the 0.45 spacing of the uniform mode),
+ * density the value every generated vertex carries.  Where the reference raises ZeroDivisionError -- an edge of 0.5 - 1.5
+ * spacings gets round(...) == 0 interior points and (B - A) / 0 -- no environment can be built:
+ *   seeds_host   [n_envs] nullable: the seed of every ring (NULL: seed0 + k), so that a caller can leave those seeds out
+ *   raises_host  [n_envs] nullable: 1 where calculate_density raises for that ring
+ *   out          nullable: NULL = probe only (fills raises_host, builds nothing)
+ * Returns MESHENV_E_STATE, *out = NULL and raises_host filled if any ring raises (MeshVecEnv.from_random_density probes a
+ * seed range first and then passes the seeds that are defined).  cos / sin of the edge directions come from the host
+ * libm (integer pixel offsets: a finite table), so the rings are the reference's bit for bit.
+ */
+int meshenv_create_random_density(int device, int n_envs, uint64_t seed0, const uint64_t *seeds_host, int num_verts,
+                                  double base_length, double density, const MeshEnvParams *params, void *stream, MeshEnv **out,
+                                  uint8_t *raises_host);
+
+/*
+ * Density.calculate_density + clockwise rule + / 100 for EXPLICIT pixel polygons with per-vertex densities (handle-free,
+ * synchronous; the drawn-domain route of ui/tk-ui.py):
+ *   poly_offsets_host [n_polys+1], pixels_host [2*total] float64 (x, y), integer_pixels != 0: the coordinates are Python
+ *   ints (the UI's event coordinates; then every value must be integral) -- the reference's arithmetic differs between
+ *   int and float operands (exact int squares and an int 0 in atan2 against pow(x, 2.0) and -0.0),
+ *   densities_host [total] nullable (1.0),
+ *   count_host [n_polys] ring lengths, status_host [n_polys]: 0 ok, 1 the reference raises ZeroDivisionError, 2 more than
+ *   2048 ring points, 3 fewer than 3 distinct pixels; xy_host [2*cap_points] nullable: the rings of the polygons with
+ *   status 0, back to back in polygon order (MESHENV_E_RANGE if they do not fit).  3..256 vertices per polygon.
+ */
+int meshenv_density_rings(int device, int n_polys, const int32_t *poly_offsets_host, const double *pixels_host, int integer_pixels,
+                          const double *densities_host, double base_length, int32_t *count_host, uint8_t *status_host,
+                          double *xy_host, int64_t cap_points);
+
 /* Host-side readout of one domain of the handle's table (synchronises the stream): xy_host[2*cap_points] receives the
  * ring, *n_out its length, consts_host[3] (nullable) original_area, estimated_area_range[0]**2, [1]**2. */
 int meshenv_get_domain(MeshEnv *h, int domain, double *xy_host, int cap_points, int32_t *n_out, double *consts_host);

@@ -15,6 +15,7 @@ ST_LOG_OVERFLOW = 2
 MOVE_OK, MOVE_NONE, MOVE_RAISES, MOVE_NEEDS_SMOOTHING, MOVE_SMOOTH_RAISES = 0, 1, 2, 3, 4
 SMOOTH_SKIPPED, SMOOTH_LOG_OVERFLOW, SMOOTH_DEGREE, SMOOTH_NOT_FINISHED, SMOOTH_INDEX_ERROR, SMOOTH_RAISES = -1, -2, -3, -4, -5, -6
 SMOOTH_NONFINITE = -7
+E_ARG, E_HIP, E_RANGE, E_STATE = -1, -2, -3, -4
 
 
 class MeshEnvParams(C.Structure):
@@ -43,7 +44,7 @@ EXPORTS = [
     "meshenv_actor_forward", "meshenv_actor_sample", "meshenv_get_last_episode", "meshenv_element_quality",
     "meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid", "meshenv_step_kernel",
     "meshenv_create_random", "meshenv_get_domain", "meshenv_smooth", "meshenv_smooth_final", "meshenv_get_not_valid_ids", "meshenv_step_actor",
-    "meshenv_libm_exact",
+    "meshenv_libm_exact", "meshenv_create_random_density", "meshenv_density_rings",
 ]
 
 
@@ -82,6 +83,11 @@ def load():
     L.meshenv_create_random.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_double, C.POINTER(MeshEnvParams), vp,
                                         C.POINTER(vp)]
     L.meshenv_create_random.restype = C.c_int
+    L.meshenv_create_random_density.argtypes = [C.c_int, C.c_int, C.c_uint64, vp, C.c_int, C.c_double, C.c_double,
+                                                C.POINTER(MeshEnvParams), vp, C.POINTER(vp), vp]
+    L.meshenv_create_random_density.restype = C.c_int
+    L.meshenv_density_rings.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_double, vp, vp, vp, C.c_int64]
+    L.meshenv_density_rings.restype = C.c_int
     L.meshenv_get_domain.argtypes = [vp, C.c_int, vp, C.c_int, i32p, vp]
     L.meshenv_get_domain.restype = C.c_int
     L.meshenv_destroy.argtypes = [vp]

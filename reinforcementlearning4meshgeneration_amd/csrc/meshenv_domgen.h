@@ -70,16 +70,17 @@ struct GenScratch {
 // clockwise_angle / math.cos / math.sin with its own libm -- the reference's -- once per offset (dir_tab, meshenv_hip.hip:
 // fill_direction_table) or once per edge (edge_dir, explicit polygons): the device result is the reference's bit for bit.
 struct DensScratch {
-    int px[kGenMaxVerts * 4], py[kGenMaxVerts * 4];   // deduplicated polygon, pixels (explicit polygons: up to 256 vertices)
+    double px[kGenMaxVerts * 4], py[kGenMaxVerts * 4];   // deduplicated polygon, pixels (explicit polygons: up to 256 vertices)
     double dens[kGenMaxVerts * 4];
     double2 dir[kGenMaxVerts * 4];                     // (cos, sin) of edge i
-    double A[kGenMaxVerts * 4], E[kGenMaxVerts * 4], L[kGenMaxVerts * 4];
+    double A[kGenMaxVerts * 4], E[kGenMaxVerts * 4], L[kGenMaxVerts * 4];   // L: filled by the caller (edge lengths)
     int X[kGenMaxVerts * 4], cnt[kGenMaxVerts * 4], off[kGenMaxVerts * 4 + 1];
     double2 res[kDensMaxPts];
 };
 constexpr int kDensMaxVerts = kGenMaxVerts * 4;
 
-// m polygon vertices are in d->px / py / dens (dict-deduplicated, m >= 3) and their edge directions in d->dir.
+// m polygon vertices are in d->px / py / dens (dict-deduplicated, m >= 3), the directions of their edges in d->dir and
+// the edge lengths in d->L (edge i = vertex i - 1 -> vertex i).
 // Returns the number of ring points (kWrite: written to out_xy), 0 with *status = 1 where the reference raises
 // ZeroDivisionError, 0 with *status = 2 when the ring does not fit kDensMaxPts.
 template <bool kWrite>
@@ -89,12 +90,11 @@ __device__ __forceinline__ int density_ring(DensScratch *d, int m, double base_l
     for (int i = lane; i < m; i += 64) {
         const int ip = i == 0 ? m - 1 : i - 1;
         const double B = d->dens[i] * base_length, A = d->dens[ip] * base_length;
-        const long long dx = (long long)d->px[ip] - d->px[i], dy = (long long)d->py[ip] - d->py[i];
-        const double L = sqrt((double)(dx * dx + dy * dy));          // math.sqrt of an exact int
+        const double L = d->L[i];
         const double xr = rint((2 * L - A - B) / (A + B));            // round(): to nearest, ties to even
         const int x = (int)xr;
         zero = zero || x == 0;
-        d->A[i] = A; d->L[i] = L; d->X[i] = x;
+        d->A[i] = A; d->X[i] = x;
         d->E[i] = x != 0 ? (B - A) / xr : 0.0;
         d->cnt[i] = (x > 0 ? x : 0) + 1;                               // range(x) offsets, then L
     }
@@ -128,7 +128,7 @@ __device__ __forceinline__ int density_ring(DensScratch *d, int m, double base_l
         const double A = d->A[e], E = d->E[e], L = d->L[e];
         const int x = d->X[e], c = d->cnt[e], o = d->off[e];
         const double2 cs = d->dir[e];
-        const double bx = (double)d->px[ep], by = (double)d->py[ep];
+        const double bx = d->px[ep], by = d->py[ep];
         for (int j = lane; j < c; j += 64) {
             // A * (j + 1) + e * (j ** 2 + j) / 2  -- float * int, float * int, / 2, +
             const double t = j < x ? A * (double)(j + 1) + (E * (double)(j * j + j)) / 2 : L;
@@ -160,7 +160,8 @@ __device__ __forceinline__ int density_ring(DensScratch *d, int m, double base_l
 }
 
 // dict keyed by coordinates over n pixel vertices (px, py, dens in `src`): first position, last density; compacted into d.
-__device__ __forceinline__ int density_dedupe(DensScratch *d, const int *sx, const int *sy, const double *sd, double dens_all,
+template <typename T>
+__device__ __forceinline__ int density_dedupe(DensScratch *d, const T *sx, const T *sy, const double *sd, double dens_all,
                                               int n, int lane)
 {
     int m = 0;
@@ -179,7 +180,7 @@ __device__ __forceinline__ int density_dedupe(DensScratch *d, const int *sx, con
         const unsigned long long mk = __ballot(first);
         if (first) {
             const int r = m + __popcll(mk & ((1ULL << lane) - 1ULL));
-            d->px[r] = sx[i]; d->py[r] = sy[i]; d->dens[r] = dv;
+            d->px[r] = (double)sx[i]; d->py[r] = (double)sy[i]; d->dens[r] = dv;
         }
         m += __popcll(mk);
     }
@@ -188,16 +189,18 @@ __device__ __forceinline__ int density_dedupe(DensScratch *d, const int *sx, con
     return m;
 }
 
-// Explicit pixel polygons (meshenv_density_rings): polygon k = vertices [poly_off[k], poly_off[k + 1]) of px / py / dens,
-// edge directions per input vertex pair from the host (edge_dir[poly_off[k] * ... ] is indexed by DEDUPLICATED vertex, see
-// the host side).  count[k] = ring length, status[k] = 0 ok / 1 raises / 2 too long / 3 fewer than 3 distinct vertices.
+// Explicit pixel polygons (meshenv_density_rings): polygon k = vertices [poly_off[k], poly_off[k + 1]) of pxy / dens;
+// edge_dir / edge_len: direction (cos, sin) and length of the edge INTO deduplicated vertex r of polygon k at index
+// poly_off[k] + r, from the host's libm.  count[k] = ring length, status[k] = 0 ok / 1 raises / 2 too long / 3 fewer than
+// 3 distinct vertices.
 template <bool kWrite>
 __global__ void __launch_bounds__(64)
-k_density_rings(int n, const int32_t *poly_off, const int32_t *pxy, const double *dens, const double2 *edge_dir, double base_length,
-                const int32_t *out_off, double2 *out_xy, int32_t *count, unsigned char *status)
+k_density_rings(int n, const int32_t *poly_off, const double *pxy, const double *dens, const double2 *edge_dir,
+                const double *edge_len, double base_length, const int32_t *out_off, double2 *out_xy, int32_t *count,
+                unsigned char *status)
 {
     __shared__ DensScratch d;
-    __shared__ int sx[kDensMaxVerts], sy[kDensMaxVerts];
+    __shared__ double sx[kDensMaxVerts], sy[kDensMaxVerts];
     const int k = blockIdx.x, lane = threadIdx.x;
     const int o = poly_off[k], nv = poly_off[k + 1] - o;
     for (int i = lane; i < nv; i += 64) { sx[i] = pxy[2 * (o + i)]; sy[i] = pxy[2 * (o + i) + 1]; }
@@ -207,7 +210,7 @@ k_density_rings(int n, const int32_t *poly_off, const int32_t *pxy, const double
     int st = 0, c = 0;
     if (m < 3) st = 3;
     else {
-        for (int i = lane; i < m; i += 64) d.dir[i] = edge_dir[o + i];
+        for (int i = lane; i < m; i += 64) { d.dir[i] = edge_dir[o + i]; d.L[i] = edge_len[o + i]; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         c = density_ring<kWrite>(&d, m, base_length, lane, kWrite ? out_xy + out_off[k] : nullptr, &st);
@@ -366,10 +369,11 @@ __device__ __forceinline__ int gen_ring(GenScratch *g, const GenParams &P, unsig
             bool out_of_table = false;
             for (int i = lane; i < m; i += 64) {
                 const int ip = i == 0 ? m - 1 : i - 1;
-                const int dx = dsc->px[i] - dsc->px[ip], dy = dsc->py[i] - dsc->py[ip];   // clockwise_angle(prev, i)
+                const int dx = (int)(dsc->px[i] - dsc->px[ip]), dy = (int)(dsc->py[i] - dsc->py[ip]);   // clockwise_angle(prev, i)
                 const bool in = dx >= -R && dx <= R && dy >= -R && dy <= R;
                 out_of_table = out_of_table || !in;
                 dsc->dir[i] = in ? P.dir_tab[(size_t)(dx + R) * W + (dy + R)] : make_double2(1.0, 0.0);
+                dsc->L[i] = sqrt((double)(dx * dx + dy * dy));   // pixel coordinates are Python ints: math.sqrt of an exact int
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -415,11 +415,12 @@ int meshenv_create(int device, int n_domains, const int32_t *dom_offsets_host, c
                        stream, nullptr, out);
 }
 
-// clockwise_angle(a, b) of ui/tk-ui.py:185-192 and its cosine / sine, for the integer pixel offset (dx, dy) = b - a: the
-// host libm's values -- the reference's -- in the reference's expression order (domains.clockwise_angle).
-static void edge_direction(int dx, int dy, double *cs)
+// clockwise_angle(a, b) of ui/tk-ui.py:185-192 and its cosine / sine for the offset (dx, dy) = b - a: the host libm's
+// values -- the reference's -- in the reference's expression order (domains.clockwise_angle).  integer: the coordinates
+// are Python ints, so -(b[1] - a[1]) of a zero difference is the int 0, i.e. +0.0 in atan2 (a float difference gives -0.0).
+static void edge_direction(double dx, double dy, bool integer, double *cs)
 {
-    volatile double ny = -(double)dy, x = (double)dx;        // volatile: the calls must reach the running libm
+    volatile double ny = (integer && dy == 0) ? 0.0 : -dy, x = dx;   // volatile: the calls must reach the running libm
     const double theta = -std::atan2(ny, x);
     volatile double angle = std::copysign(1.0, theta) >= 0 ? theta : 2 * 3.141592653589793 + theta;
     cs[0] = std::cos(angle);
@@ -464,7 +465,7 @@ static int create_random_impl(const char *fn, int device, int n_envs, GenParams 
         const int R = (int)std::ceil(4 * gp.ave_radius) + 1, W = 2 * R + 1;
         std::vector<double> tab((size_t)W * W * 2);
         for (int dx = -R; dx <= R; dx++)
-            for (int dy = -R; dy <= R; dy++) edge_direction(dx, dy, &tab[((size_t)(dx + R) * W + (dy + R)) * 2]);
+            for (int dy = -R; dy <= R; dy++) edge_direction((double)dx, (double)dy, true, &tab[((size_t)(dx + R) * W + (dy + R)) * 2]);
         ok = hipMalloc((void **)&d_tab, sizeof(double2) * (size_t)W * W) == hipSuccess &&
              hipMemcpy(d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice) == hipSuccess &&
              hipMalloc((void **)&d_raises, (size_t)n_envs) == hipSuccess && hipMemset(d_raises, 0, (size_t)n_envs) == hipSuccess;
@@ -548,7 +549,7 @@ int meshenv_create_random_density(int device, int n_envs, uint64_t seed0, const 
     return create_random_impl("meshenv_create_random_density", device, n_envs, gp, seeds_host, params, stream, out, raises_host);
 }
 
-int meshenv_density_rings(int device, int n_polys, const int32_t *poly_offsets_host, const int32_t *pixels_host,
+int meshenv_density_rings(int device, int n_polys, const int32_t *poly_offsets_host, const double *pixels_host, int integer_pixels,
                           const double *densities_host, double base_length, int32_t *count_host, uint8_t *status_host,
                           double *xy_host, int64_t cap_points)
 {
@@ -559,49 +560,60 @@ int meshenv_density_rings(int device, int n_polys, const int32_t *poly_offsets_h
         const int nv = poly_offsets_host[k + 1] - poly_offsets_host[k];
         if (nv < 3 || nv > kDensMaxVerts) return MESHENV_E_ARG;
     }
-    // Edge directions from the host libm.  The device deduplicates repeated pixels (the reference's dict), so the
-    // direction of the edge INTO deduplicated vertex r is computed here for the same deduplicated list.
-    std::vector<double> dir((size_t)total_in * 2, 0.0);
+    if (integer_pixels)
+        for (int i = 0; i < 2 * total_in; i++)
+            if (pixels_host[i] != std::floor(pixels_host[i]) || std::fabs(pixels_host[i]) > 1e9) return MESHENV_E_ARG;
+    // Edge directions and lengths from the host libm.  The device deduplicates repeated pixels (the reference's dict), so
+    // the edge INTO deduplicated vertex r is computed here for the same deduplicated list.
+    std::vector<double> dir((size_t)total_in * 2, 0.0), len((size_t)total_in, 0.0);
+    volatile double two = 2.0;
     for (int k = 0; k < n_polys; k++) {
         const int o = poly_offsets_host[k], nv = poly_offsets_host[k + 1] - o;
+        const double *P = pixels_host + 2 * (size_t)o;
         std::vector<int> keep;
         for (int i = 0; i < nv; i++) {
             bool first = true;
-            for (int j = 0; j < i && first; j++) first = !(pixels_host[2 * (o + j)] == pixels_host[2 * (o + i)] && pixels_host[2 * (o + j) + 1] == pixels_host[2 * (o + i) + 1]);
+            for (int j = 0; j < i && first; j++) first = !(P[2 * j] == P[2 * i] && P[2 * j + 1] == P[2 * i + 1]);
             if (first) keep.push_back(i);
         }
         const int m = (int)keep.size();
         for (int r = 0; r < m; r++) {
             const int i = keep[(size_t)r], ip = keep[(size_t)(r == 0 ? m - 1 : r - 1)];
-            edge_direction(pixels_host[2 * (o + i)] - pixels_host[2 * (o + ip)], pixels_host[2 * (o + i) + 1] - pixels_host[2 * (o + ip) + 1],
-                           &dir[2 * (size_t)(o + r)]);
+            const double dx = P[2 * i] - P[2 * ip], dy = P[2 * i + 1] - P[2 * ip + 1];
+            edge_direction(dx, dy, integer_pixels != 0, &dir[2 * (size_t)(o + r)]);
+            // distance(): math.sqrt((p1[0] - p2[0]) ** 2 + (p1[1] - p2[1]) ** 2) -- exact int arithmetic for Python ints,
+            // libm pow for floats
+            len[(size_t)(o + r)] = integer_pixels ? std::sqrt(dx * dx + dy * dy) : std::sqrt(std::pow(-dx, two) + std::pow(-dy, two));
         }
     }
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) return MESHENV_E_HIP;
-    int32_t *d_off = nullptr, *d_px = nullptr, *d_cnt = nullptr, *d_ooff = nullptr;
-    double *d_dens = nullptr;
+    int32_t *d_off = nullptr, *d_cnt = nullptr, *d_ooff = nullptr;
+    double *d_dens = nullptr, *d_px = nullptr, *d_len = nullptr;
     double2 *d_dir = nullptr, *d_out = nullptr;
     unsigned char *d_st = nullptr;
     int rc = MESHENV_OK;
     auto H = [&](hipError_t e) { if (e != hipSuccess && rc == MESHENV_OK) rc = MESHENV_E_HIP; return e == hipSuccess; };
     H(hipMalloc((void **)&d_off, sizeof(int32_t) * ((size_t)n_polys + 1)));
-    H(hipMalloc((void **)&d_px, sizeof(int32_t) * 2 * (size_t)total_in));
+    H(hipMalloc((void **)&d_px, sizeof(double) * 2 * (size_t)total_in));
     H(hipMalloc((void **)&d_cnt, sizeof(int32_t) * (size_t)n_polys));
     H(hipMalloc((void **)&d_ooff, sizeof(int32_t) * ((size_t)n_polys + 1)));
     H(hipMalloc((void **)&d_dir, sizeof(double2) * (size_t)total_in));
+    H(hipMalloc((void **)&d_len, sizeof(double) * (size_t)total_in));
     H(hipMalloc((void **)&d_st, (size_t)n_polys));
     if (densities_host) H(hipMalloc((void **)&d_dens, sizeof(double) * (size_t)total_in));
     if (rc == MESHENV_OK) {
         H(hipMemcpy(d_off, poly_offsets_host, sizeof(int32_t) * ((size_t)n_polys + 1), hipMemcpyHostToDevice));
-        H(hipMemcpy(d_px, pixels_host, sizeof(int32_t) * 2 * (size_t)total_in, hipMemcpyHostToDevice));
+        H(hipMemcpy(d_px, pixels_host, sizeof(double) * 2 * (size_t)total_in, hipMemcpyHostToDevice));
         H(hipMemcpy(d_dir, dir.data(), sizeof(double) * dir.size(), hipMemcpyHostToDevice));
+        H(hipMemcpy(d_len, len.data(), sizeof(double) * len.size(), hipMemcpyHostToDevice));
         if (densities_host) H(hipMemcpy(d_dens, densities_host, sizeof(double) * (size_t)total_in, hipMemcpyHostToDevice));
     }
     std::vector<int32_t> ooff((size_t)n_polys + 1, 0);
     if (rc == MESHENV_OK) {
-        hipLaunchKernelGGL(k_density_rings<false>, dim3(n_polys), dim3(64), 0, nullptr, n_polys, (const int32_t *)d_off, (const int32_t *)d_px,
-                           (const double *)d_dens, (const double2 *)d_dir, base_length, (const int32_t *)nullptr, (double2 *)nullptr, d_cnt, d_st);
+        hipLaunchKernelGGL(k_density_rings<false>, dim3(n_polys), dim3(64), 0, nullptr, n_polys, (const int32_t *)d_off, (const double *)d_px,
+                           (const double *)d_dens, (const double2 *)d_dir, (const double *)d_len, base_length, (const int32_t *)nullptr,
+                           (double2 *)nullptr, d_cnt, d_st);
         H(hipGetLastError());
         H(hipDeviceSynchronize());
         H(hipMemcpy(count_host, d_cnt, sizeof(int32_t) * (size_t)n_polys, hipMemcpyDeviceToHost));
@@ -615,15 +627,16 @@ int meshenv_density_rings(int device, int n_polys, const int32_t *poly_offsets_h
             H(hipMalloc((void **)&d_out, sizeof(double2) * (size_t)total_out));
             H(hipMemcpy(d_ooff, ooff.data(), sizeof(int32_t) * ((size_t)n_polys + 1), hipMemcpyHostToDevice));
             if (rc == MESHENV_OK) {
-                hipLaunchKernelGGL(k_density_rings<true>, dim3(n_polys), dim3(64), 0, nullptr, n_polys, (const int32_t *)d_off, (const int32_t *)d_px,
-                                   (const double *)d_dens, (const double2 *)d_dir, base_length, (const int32_t *)d_ooff, d_out, d_cnt, d_st);
+                hipLaunchKernelGGL(k_density_rings<true>, dim3(n_polys), dim3(64), 0, nullptr, n_polys, (const int32_t *)d_off, (const double *)d_px,
+                                   (const double *)d_dens, (const double2 *)d_dir, (const double *)d_len, base_length, (const int32_t *)d_ooff,
+                                   d_out, d_cnt, d_st);
                 H(hipGetLastError());
                 H(hipDeviceSynchronize());
                 H(hipMemcpy(xy_host, d_out, sizeof(double2) * (size_t)total_out, hipMemcpyDeviceToHost));
             }
         }
     }
-    for (void *p : {(void *)d_off, (void *)d_px, (void *)d_cnt, (void *)d_ooff, (void *)d_dens, (void *)d_dir, (void *)d_out, (void *)d_st})
+    for (void *p : {(void *)d_off, (void *)d_px, (void *)d_cnt, (void *)d_ooff, (void *)d_dens, (void *)d_dir, (void *)d_len, (void *)d_out, (void *)d_st})
         if (p) (void)hipFree(p);
     return rc;
 }

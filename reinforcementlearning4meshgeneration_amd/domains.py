@@ -220,6 +220,55 @@ def random_domain(seed: int, num_verts: int | None = None, edge: float = 0.45) -
     return [(round(x, 4), round(y, 4)) for x, y in pts]
 
 
+def random_density_domain(seed: int, base_length: float = 45.0, density: float = 1.0,
+                          num_verts: int | None = None) -> List[Point]:
+    """Config-5 domain by the REFERENCE's own route: random_polygon_px(seed) -> calculate_density (every vertex at
+    ``density``, ``base_length`` in pixels) -> clockwise rule -> / 100.  Raises ZeroDivisionError where the reference's
+    calculate_density does (an edge of 0.5 - 1.5 spacings).  meshenv_create_random_density computes the same ring on the
+    device, bit for bit (tests/test_gpu_domgen.py)."""
+    px = random_polygon_px(seed, num_verts)
+    return density_domain(px, base_length, [density] * len(px))
+
+
+def device_density_rings(polygons_px: Sequence[Sequence[Tuple[int, int]]], base_length: float,
+                         densities: Sequence[Sequence[float]] | None = None, device: int = 0):
+    """calculate_density + clockwise rule + / 100 on the DEVICE for explicit pixel polygons (meshenv_density_rings).
+    Returns (rings, status): rings[k] = [n_k, 2] float64 array, or None where status[k] != 0 (1: the reference raises
+    ZeroDivisionError; 2: more than 2048 ring points; 3: fewer than 3 distinct pixels)."""
+    import ctypes as C
+
+    from . import _capi
+    L = _capi.load()
+    n = len(polygons_px)
+    offs = np.zeros(n + 1, np.int32)
+    for k, poly in enumerate(polygons_px):
+        offs[k + 1] = offs[k] + len(poly)
+    flat = [c for poly in polygons_px for p in poly for c in p]
+    is_int = 1 if all(isinstance(c, (int, np.integer)) for c in flat) else 0   # Python ints and floats take different arithmetic
+    pix = np.ascontiguousarray(flat, np.float64)
+    dens = None if densities is None else np.ascontiguousarray([d for ds in densities for d in ds], np.float64)
+    cnt = np.zeros(n, np.int32)
+    st = np.zeros(n, np.uint8)
+    rc = L.meshenv_density_rings(device, n, offs.ctypes.data, pix.ctypes.data, is_int, None if dens is None else dens.ctypes.data,
+                                 float(base_length), cnt.ctypes.data, st.ctypes.data, None, C.c_int64(0))
+    if rc != 0:
+        raise _capi.MeshEnvError(f"meshenv_density_rings failed (code {rc})")
+    total = int(cnt[st == 0].sum())
+    xy = np.zeros(2 * max(total, 1), np.float64)
+    rc = L.meshenv_density_rings(device, n, offs.ctypes.data, pix.ctypes.data, is_int, None if dens is None else dens.ctypes.data,
+                                 float(base_length), cnt.ctypes.data, st.ctypes.data, xy.ctypes.data, C.c_int64(total))
+    if rc != 0:
+        raise _capi.MeshEnvError(f"meshenv_density_rings failed (code {rc})")
+    rings, o = [], 0
+    for k in range(n):
+        if st[k] == 0:
+            rings.append(xy[2 * o:2 * (o + int(cnt[k]))].reshape(-1, 2).copy())
+            o += int(cnt[k])
+        else:
+            rings.append(None)
+    return rings, st
+
+
 # --------------------------------------------------------------------------- constants
 
 def _distance(a: Point, b: Point) -> float:

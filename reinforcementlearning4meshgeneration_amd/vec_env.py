@@ -202,6 +202,66 @@ class MeshVecEnv:
         self._finish_init()
         return self
 
+    @classmethod
+    def from_random_density(cls, n_envs: int, seed: int, base_length: float = 45.0, density: float = 1.0, device: int = 0,
+                            num_verts: int = 0, log_capacity: int = 0, auto_reset: bool = True, fail_limit: int = 100,
+                            lazy_infos: bool = True, seeds: Optional[Sequence[int]] = None):
+        """n_envs environments on GenerateRandomPolygon rings densified by the REFERENCE's Density.calculate_density
+        (ui/tk-ui.py:252-276) on the device (meshenv_create_random_density); ``domains.random_density_domain(seed_k,
+        base_length)`` is the same ring computed on the host.  calculate_density raises ZeroDivisionError for polygons with
+        an edge of 0.5 - 1.5 spacings, so not every seed gives a domain: without ``seeds`` the seeds ``seed, seed + 1, ...``
+        are probed on the device in blocks and the first n_envs that are defined are used (``self.seeds`` lists them);
+        with ``seeds`` exactly those are used and an undefined one is an error."""
+        import torch
+        L = _capi.load()
+        if not torch.cuda.is_available():
+            raise _capi.MeshEnvError("MeshVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                     "this package has no CPU fallback")
+        n_envs = int(n_envs)
+        dev = torch.device("cuda", device)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if seeds is None:
+                found, nxt = [], int(seed)
+                while len(found) < n_envs:
+                    blk = max(256, 2 * (n_envs - len(found)))
+                    rz = np.zeros(blk, np.uint8)
+                    rc = L.meshenv_create_random_density(device, blk, C.c_uint64(nxt), None, int(num_verts), float(base_length),
+                                                         float(density), None, C.c_void_p(stream), None, rz.ctypes.data)
+                    if rc not in (0, _capi.E_STATE) or (rc == _capi.E_STATE and not rz.any()):
+                        msg = L.meshenv_last_error(None)
+                        raise _capi.MeshEnvError(f"meshenv_create_random_density (probe) failed (code {rc}): {msg.decode() if msg else ''}")
+                    found.extend(int(nxt + k) for k in np.nonzero(rz == 0)[0])
+                    nxt += blk
+                    if nxt - int(seed) > 256 * n_envs + 65536:
+                        raise _capi.MeshEnvError("from_random_density: too few polygons on which calculate_density is defined "
+                                                 f"at base_length {base_length}")
+                seeds = found[:n_envs]
+            seeds = np.ascontiguousarray(seeds, np.uint64)
+            if seeds.shape != (n_envs,):
+                raise ValueError(f"seeds must have {n_envs} entries")
+            self = cls.__new__(cls)
+            self._torch, self._L = torch, L
+            self.num_envs, self.device = n_envs, dev
+            self.auto_reset, self.lazy_infos, self.log_capacity = bool(auto_reset), bool(lazy_infos), int(log_capacity)
+            self.env_domain = np.arange(n_envs, dtype=np.int32)
+            self._domains = self._constants = None
+            self.seeds = seeds.copy()
+            prm = _capi.default_params()
+            prm.log_capacity = self.log_capacity
+            prm.fail_limit = int(fail_limit)
+            self._handle = C.c_void_p()
+            rz = np.zeros(n_envs, np.uint8)
+            rc = L.meshenv_create_random_density(device, n_envs, C.c_uint64(0), seeds.ctypes.data, int(num_verts), float(base_length),
+                                                 float(density), C.byref(prm), C.c_void_p(stream), C.byref(self._handle),
+                                                 rz.ctypes.data)
+        if rc != 0:
+            msg = L.meshenv_last_error(None)
+            raise _capi.MeshEnvError(f"meshenv_create_random_density failed (code {rc}): {msg.decode() if msg else ''}"
+                                     + (f"; undefined seeds: {seeds[rz != 0][:8].tolist()}" if rz.any() else ""))
+        self._finish_init()
+        return self
+
     def get_domain(self, d: int):
         """(ring [n, 2] float64, (original_area, est_min_l ** 2, est_crit_l ** 2)) of domain d as the device holds it."""
         cap = self.max_ring

@@ -122,3 +122,86 @@ def test_config5_full_size_65536_generated_envs_sampled_oracle_shadow():
     assert cnt["steps"] == n * T and cnt["valid"] > 0.005 * n * T
     print(f"config 5 at full size: {n} envs x {T} steps, {cnt['valid']} valid extractions, max ring {env.max_ring}")
     env.close()
+
+
+# ------------------------------------------------------------------------------------------------ the reference's densifier
+def _fx():
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    return json.load(open(os.path.join(GOLDEN_DIR, "domain_pipeline.json")))
+
+
+def test_device_calculate_density_equals_the_reference_vectors():
+    """Density.calculate_density (ui/tk-ui.py:252-276) + clockwise rule + / 100 on the device (meshenv_density_rings) against
+    the vectors recorded from the reference's own function (tests/golden/domain_pipeline.json: 8 calculate_density cases
+    with per-vertex densities, 7 whole-pipeline cases): bit for bit, ZeroDivisionError cases reported as status 1."""
+    from reinforcementlearning4meshgeneration_amd import domains as D
+    fx = _fx()
+    polys, dens, bl, want = [], [], [], []
+    for case in fx["calculate_density"]:
+        polys.append([tuple(p) for p in case["points"]]); dens.append(case["densities"]); bl.append(case["base_length"])
+        want.append(None if case["result"] is None else
+                    [(p[0] / 100, p[1] / 100) for p in D.normalise_clockwise([tuple(p) for p in case["result"]])])
+    for case in fx["pipeline"]:
+        polys.append([tuple(p) for p in case["raw"]]); dens.append([1.0] * len(case["raw"])); bl.append(case["base_length"])
+        want.append(None if case["ring"] is None else [tuple(p) for p in case["ring"]])
+    n_ok = n_raise = 0
+    for k in range(len(polys)):                       # one call per case: base_length differs
+        rings, st = D.device_density_rings([polys[k]], bl[k], [dens[k]])
+        if want[k] is None:
+            assert st[0] == 1 and rings[0] is None, (k, st)
+            n_raise += 1
+        else:
+            assert st[0] == 0, (k, st)
+            assert rings[0].shape == (len(want[k]), 2) and np.array_equal(rings[0], np.asarray(want[k], np.float64)), k
+            n_ok += 1
+    assert n_ok >= 8 and n_raise >= 2
+
+
+def test_device_density_mode_equals_host_restatement_on_generated_polygons():
+    """meshenv_create_random_density: generator + calculate_density + orientation on the device for a block of 49 152 + 16 384 seeds
+    at two spacings; the raise flags equal the host restatement's ZeroDivisionError seed by seed, and the rings of the
+    envs built from the defined seeds are domains.random_density_domain(seed, base_length) bit for bit."""
+    import ctypes as C
+    import torch
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv, _capi
+    from reinforcementlearning4meshgeneration_amd.domains import random_density_domain
+    L = _capi.load()
+    total_defined = 0
+    for base_length, seed0, blk in ((20.0, 300_000, 49152), (12.0, 900_000, 16384)):
+        rz = np.zeros(blk, np.uint8)
+        rc = L.meshenv_create_random_density(0, blk, C.c_uint64(seed0), None, 0, base_length, 1.0, None, None, None, rz.ctypes.data)
+        assert rc in (0, _capi.E_STATE)
+        host_raises = np.zeros(blk, np.uint8)
+        host_rings = {}
+        for k in range(blk):
+            try:
+                host_rings[k] = random_density_domain(seed0 + k, base_length)
+            except ZeroDivisionError:
+                host_raises[k] = 1
+        assert np.array_equal(rz, host_raises), np.nonzero(rz != host_raises)[0][:8]
+        defined = np.nonzero(rz == 0)[0]
+        assert len(defined) > 50
+        env = MeshVecEnv.from_random_density(len(defined), 0, base_length=base_length, seeds=seed0 + defined)
+        for j, k in enumerate(defined):
+            ring, _ = env.get_domain(j)
+            host = np.asarray(host_rings[int(k)], np.float64)
+            assert ring.shape == host.shape and np.array_equal(ring, host), (base_length, int(k))
+            assert len(host) % 2 == 0
+        total_defined += len(defined)
+        env.close()
+    print("density mode: rings identical to the host restatement on", total_defined, "generated polygons")
+    assert total_defined >= 8192
+    # and the seed search of the Python wrapper
+    env = MeshVecEnv.from_random_density(512, 300_000, base_length=20.0)
+    assert len(env.seeds) == 512 and (np.diff(env.seeds.astype(np.int64)) > 0).all()
+    ring, _ = env.get_domain(5)
+    assert np.array_equal(ring, np.asarray(random_density_domain(int(env.seeds[5]), 20.0), np.float64))
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    lo = torch.tensor([-1.0, 0.2, 0.3], device="cuda"); hi = torch.tensor([1.0, 1.0, 1.2], device="cuda")
+    valid0 = env.counters()["valid"]
+    for _ in range(40):
+        env.step((lo + (hi - lo) * torch.rand((512, 3), device="cuda", generator=g)).contiguous())
+    assert env.counters()["valid"] - valid0 > 200       # the rings are meshable domains
+    env.close()
