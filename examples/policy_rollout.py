@@ -27,8 +27,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--domain", default="d1", choices=["d1", "boundary0"])
     ap.add_argument("--deterministic", action="store_true")
-    ap.add_argument("--actor", default="fused", choices=["one-launch", "fused", "fused-ext-noise", "graph", "eager"],
-                    help="one-launch = env step + actor forward in ONE kernel per vector step (meshenv_step_actor); "
+    ap.add_argument("--chunk", type=int, default=32, help="t-steps: vector steps per launch")
+    ap.add_argument("--actor", default="fused", choices=["t-steps", "one-launch", "fused", "fused-ext-noise", "graph", "eager"],
+                    help="t-steps = --chunk vector steps of the closed loop per launch (meshenv_step_actor_multi); "
+                         "one-launch = env step + actor forward in ONE kernel per vector step (meshenv_step_actor); "
                          "fused = the hand-written HIP actor kernel, exploration noise drawn inside it (one launch); "
                          "fused-ext-noise = same kernel fed by torch's normal_() (two launches); graph = the torch MLP captured as one HIP "
                          "graph; eager = the torch MLP launch by launch")
@@ -63,7 +65,7 @@ def main():
 
     env = MeshVecEnv([dom], n_envs=args.envs, device=0)
     obs = env.reset()          # env.obs: the kernel always writes observations into this tensor
-    if args.actor.startswith("fused") or args.actor == "one-launch":
+    if args.actor.startswith("fused") or args.actor in ("one-launch", "t-steps"):
         from reinforcementlearning4meshgeneration_amd.actor import FusedActor
         fused = FusedActor.from_torch([trunk[0], trunk[2], trunk[4]], mu_head, log_std_head)
         actions = torch.empty((args.envs, 3), dtype=torch.float32, device=dev)
@@ -73,7 +75,7 @@ def main():
         def policy(o):
             if args.deterministic:
                 return fused.forward(o, None, out=actions)
-            if args.actor in ("fused", "one-launch"):
+            if args.actor in ("fused", "one-launch", "t-steps"):
                 draw[0] += 1
                 return fused.sample(o, 999, draw[0], out=actions)
             return fused.forward(o, noise.normal_(), out=actions)
@@ -95,7 +97,21 @@ def main():
     else:
         policy = act
     # timed loop: policy + step only (one, two or three launches per vector step)
-    if args.actor == "one-launch":
+    if args.actor == "t-steps":
+        nxt = policy(obs)
+        T = args.chunk
+        args.warmup = (args.warmup + T - 1) // T * T
+        args.steps = (args.steps + T - 1) // T * T
+        for t in range(0, args.warmup + args.steps, T):
+            if t == args.warmup:
+                torch.cuda.synchronize()
+                c0 = env.counters()
+                t0 = time.perf_counter()
+            hist = env.step_actor_T(fused, nxt, T, seed=999, counter=draw[0] + 1, sample=not args.deterministic)
+            draw[0] += T
+            nxt = hist["actions"][T]
+        obs = env.obs
+    elif args.actor == "one-launch":
         nxt = policy(obs)
         for t in range(args.warmup + args.steps):
             if t == args.warmup:

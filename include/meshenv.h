@@ -450,6 +450,21 @@ int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float
                        uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset, int sample, uint64_t seed, uint64_t counter,
                        float *actions_next_dev, float *eps_out_dev);
 
+/* T vector steps of the closed loop in ONE launch (csrc/meshenv_fused.h, k_step_group_actor_T): the workgroups of the
+ * fused kernel never talk to each other, so each loops [step its 16 envs -> actor forward] T times on its own -- one launch
+ * ramp per T steps, and the workgroups drift apart instead of waiting, every step, for the CU with the most extractions.
+ *   actions_dev   [T+1][n][3]  slice 0 = the actions of the first step (input); slice t + 1 = the policy's actions on
+ *                              the observations of step t (output: slice T feeds the next call)
+ *   obs_dev [T][n][18], reward_dev [T][n], done_dev [T][n], complete_dev [T][n], terminal_obs_dev [T][n][18] (nullable),
+ *   eps_out_dev [T][n][3] (nullable): slice t = what meshenv_step_actor would have written at step t; the noise counter of
+ *   step t is counter + t.
+ * Bit-identical to T calls of meshenv_step_actor(counter + t) on the slices (that is also what runs when the batch is not
+ * on the fused kernel: T x the one- or two-launch path).  The reference has no counterpart: its loop is SB3's
+ * collect_rollouts calling policy and env.step() alternately (rl/baselines/RL_Mesh.py:186-228). */
+int meshenv_step_actor_multi(MeshEnv *h, MeshActor *a, int T, float *actions_dev, float *obs_dev, double *reward_dev, uint8_t *done_dev,
+                         uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset, int sample, uint64_t seed, uint64_t counter,
+                         float *eps_out_dev);
+
 /*
  * Test hook: evaluate one device geometry primitive on n items (in_per_item doubles each) and copy the results
  * back, so the parity tests can compare the device primitives with the oracle's one by one.

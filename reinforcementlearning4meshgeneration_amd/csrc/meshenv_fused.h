@@ -46,4 +46,76 @@ k_step_group_actor(GroupActorArgs A)
                        A.eps_out, lds, threadIdx.x, 64 * 16);
 }
 
+// T vector steps of the closed loop in ONE launch.  The workgroups never talk to each other -- a workgroup owns 16
+// environments and runs their policy -- so nothing forces the grid back to the host between steps: each workgroup loops
+// [step its 16 envs -> barrier -> actor forward -> barrier] T times on its own.  What that buys: one launch ramp / drain per
+// T steps instead of per step, and the workgroups drift apart, so the launch no longer ends, every step, with the CU that
+// happens to hold the most extractions (tools/balance_bound.py prices that tail at ~1.8 us per step) -- the imbalance
+// averages out over T steps.  Outputs are [T][n]-shaped histories (slice t = what meshenv_step_actor would have written at
+// step t), actions [T + 1][n][3]: slice 0 is the input, slice t + 1 the policy's answer to the observations of step t; the
+// noise counter advances by one per step, so the stream equals T calls of meshenv_step_actor with counter, counter + 1, ...
+// Environment state goes through HBM between steps exactly as between launches (the same load / store code), ordered by
+// the workgroup barrier: results are bit-identical to T single-step launches (tests/test_gpu_actor.py).
+struct GroupActorArgsT {
+    GroupArgs g;             // FIRST (late_outs); g.outs = slice 0 of the [T][n] histories, g.actions = slice 0 of actions
+    ActorWeights W;
+    float *eps_out;          // [T][n][3] nullable
+    unsigned long long seed, counter;
+    int sample;
+    int T;
+    unsigned long long *dbg; // nullable: [grid][T][4] s_memrealtime stamps per workgroup and step (tools/tsteps_timeline.py)
+};
+
+#ifndef MESHENV_T_ALL3
+#define MESHENV_T_ALL3 false   // all three layers' weights requested ahead do not fit next to the loop's live values: they spill
+#endif
+template <bool kDefaultParams>
+__global__ void __launch_bounds__(64 * 16)
+k_step_group_actor_T(GroupActorArgsT A)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // (the address-space-4 reads below have no host meaning)
+    extern __shared__ double2 smem[];
+    const int T = A.T;
+    for (int t = 0; t < T; t++) {
+        // Nothing of one iteration may be carried to the next in registers: the step body derives long tables from the
+        // thread id and the arguments, and hoisted out of the loop they do not fit the 128 VGPRs of a 16-wave workgroup
+        // (inlined as it stands: 209 VGPRs spilled, 768 B of scratch per lane).  So the thread id, the step index and the
+        // kernel-argument pointer are made opaque once per iteration: everything derived from them -- the arguments
+        // included -- is loaded / recomputed inside the step and dies with it, as in the one-step kernel.
+        int tid = (int)threadIdx.x, tt = t;
+        KernArgPtr ka = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+v"(tid));
+        asm volatile("" : "+s"(tt), "+s"(ka));
+        typedef const __attribute__((address_space(4))) GroupActorArgsT *aptr;
+        const aptr Ap = (aptr)ka;
+        float *lds = (float *)((char *)smem + group_lds_bytes(Ap->g.cap, 16));
+        unsigned long long *dbg = Ap->dbg;
+        if (dbg && tid == 0) dbg[((size_t)blockIdx.x * T + tt) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        {
+            GroupArgs g = Ap->g;
+            const size_t n = (size_t)g.S.n_envs;
+            g.actions += (size_t)tt * n * 3;
+            g.step0 += (unsigned long long)tt;
+            step_group_body<16, kDefaultParams>(g, lds, tt, ka, tid);
+        }
+        asm volatile("" : "+s"(ka));
+        const aptr Bp = (aptr)ka;
+        const ActorWeights W = Bp->W;
+        ActorHead hd;
+        // (the actor gets the hardware thread id: its wave index must stay provably wave-uniform -- scalar weight addresses)
+        actor_request_weights(hd, W, threadIdx.x, MESHENV_T_ALL3);
+        if (dbg && tid == 0) dbg[((size_t)blockIdx.x * T + tt) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        __syncthreads();
+        if (dbg && tid == 0) dbg[((size_t)blockIdx.x * T + tt) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+        const size_t n = (size_t)Bp->g.S.n_envs;
+        float *eps = Bp->eps_out;
+        actor_forward_tile(W, hd, (int)n, blockIdx.x * kActEnvs, nullptr, nullptr, const_cast<float *>(Bp->g.actions) + (size_t)(tt + 1) * n * 3,
+                           Bp->sample, Bp->seed, Bp->counter + (unsigned long long)tt, eps ? eps + (size_t)tt * n * 3 : nullptr, lds,
+                           threadIdx.x, 64 * 16);
+        __syncthreads();   // the actions of step t + 1 and the environments' state are written: visible to the whole workgroup
+        if (dbg && tid == 0) dbg[((size_t)blockIdx.x * T + tt) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
 }  // namespace meshenv

@@ -56,6 +56,7 @@ struct MeshEnv {
     bool reselect_pending = false;     // a rebuild ran since the last step kernel
     bool smooth_final_ready = false;
     bool fused_ready = false;          // k_step_group_actor's LDS attribute set
+    bool fused_T_ready = false;        // k_step_group_actor_T's
     // move() API state, allocated by the first meshenv_move: not_valid_points per env
     double2 *nv_xy = nullptr;    // [E][cap]
     int32_t *nv_count = nullptr; // [E]
@@ -1584,6 +1585,61 @@ int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float
     hipLaunchKernelGGL((k_step_group_actor<true>), dim3((h->n_envs + 15) / 16), dim3(64 * 16), group_actor_lds_bytes(h->cap), h->stream, GA);
     HIP_TRY(h, hipGetLastError());
     h->steps_done += 1;
+    return MESHENV_OK;
+}
+
+int meshenv_step_actor_multi(MeshEnv *h, MeshActor *a, int T, float *actions_dev, float *obs_dev, double *reward_dev, uint8_t *done_dev,
+                         uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset, int sample, uint64_t seed, uint64_t counter,
+                         float *eps_out_dev)
+{
+    if (!h || !a) return MESHENV_E_ARG;
+    if (T <= 0 || !actions_dev || !obs_dev || !reward_dev || !done_dev || !complete_dev)
+        return fail_arg(h, "meshenv_step_actor_multi: T > 0 and non-null device pointers are required");
+    if (!a->loaded) {
+        h->err = "meshenv_step_actor_multi: the actor has no weights loaded";
+        return MESHENV_E_STATE;
+    }
+    if (a->device != h->device || a->stream != h->stream) {
+        h->err = "meshenv_step_actor_multi: env and actor must be on the same device and stream (meshenv_set_stream / meshenv_actor_set_stream)";
+        return MESHENV_E_STATE;
+    }
+    const size_t n = (size_t)h->n_envs;
+    const bool fusable = h->group == 16 && !h->spec && h->default_params && h->timing == 0 && !h->reselect_pending &&
+                         group_actor_lds_bytes(h->cap) <= 160 * 1024 && !h->S.msg;
+    if (!fusable || T == 1) {   // the same results step by step
+        for (int t = 0; t < T; t++) {
+            const int rc = meshenv_step_actor(h, a, actions_dev + (size_t)t * n * 3, obs_dev + (size_t)t * n * kObsDim, reward_dev + (size_t)t * n,
+                                              done_dev + (size_t)t * n, complete_dev + (size_t)t * n,
+                                              terminal_obs_dev ? terminal_obs_dev + (size_t)t * n * kObsDim : nullptr, auto_reset, sample, seed,
+                                              counter + (uint64_t)t, actions_dev + (size_t)(t + 1) * n * 3,
+                                              eps_out_dev ? eps_out_dev + (size_t)t * n * 3 : nullptr);
+            if (rc != MESHENV_OK) return rc;
+        }
+        return MESHENV_OK;
+    }
+    MESHENV_ON_DEVICE(h);
+    if (!h->fused_T_ready) {
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_step_group_actor_T<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        h->fused_T_ready = true;
+    }
+    GroupActorArgsT GA;
+    GA.g.S = h->S;
+    GA.g.outs.obs_out = obs_dev; GA.g.outs.reward = reward_dev; GA.g.outs.done = done_dev; GA.g.outs.complete = complete_dev;
+    GA.g.outs.term_obs = terminal_obs_dev;
+    GA.g.actions = actions_dev;
+    GA.g.step0 = (unsigned long long)h->steps_done;
+    GA.g.cap = h->cap;
+    GA.g.auto_reset = auto_reset;
+    GA.W = a->W;
+    GA.eps_out = eps_out_dev;
+    GA.seed = seed; GA.counter = counter;
+    GA.sample = sample ? 1 : 0;
+    GA.T = T;
+    GA.dbg = nullptr;
+    if (const char *dp = std::getenv("MESHENV_TSTEPS_DBG")) GA.dbg = (unsigned long long *)std::strtoull(dp, nullptr, 0);   // dev tool only
+    hipLaunchKernelGGL((k_step_group_actor_T<true>), dim3((h->n_envs + 15) / 16), dim3(64 * 16), group_actor_lds_bytes(h->cap), h->stream, GA);
+    HIP_TRY(h, hipGetLastError());
+    h->steps_done += (uint64_t)T;
     return MESHENV_OK;
 }
 

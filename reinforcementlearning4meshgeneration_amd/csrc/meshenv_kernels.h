@@ -150,10 +150,11 @@ struct EnvLoad {
 
 // (with_keys = false: the candidate keys and stamps stay in HBM -- only a step that extracts an element reads them (the
 // candidate patch of env_apply and the selection that follows), see load_keys)
-__device__ __forceinline__ EnvLoad load_env_issue(const DevState &S, int env, const bool with_keys = true)
+// (lane_in: the T-step closed-loop kernel hands its per-iteration opaque lane id down; -1 = the hardware's)
+__device__ __forceinline__ EnvLoad load_env_issue(const DevState &S, int env, const bool with_keys = true, const int lane_in = -1)
 {
     EnvLoad L;
-    const int lane = lane_id();
+    const int lane = lane_in >= 0 ? lane_in : lane_id();
     const size_t base = (size_t)env * S.cap;
     // everything below is independent: one HBM round trip
     L.s = S.scal[env];
@@ -190,9 +191,10 @@ __device__ __forceinline__ EnvLoad load_env_issue(const DevState &S, int env, co
     return L;
 }
 
-__device__ __forceinline__ void load_env_commit(Ctx &c, const DevState &S, int env, const EnvLoad &L, const bool with_keys = true)
+__device__ __forceinline__ void load_env_commit(Ctx &c, const DevState &S, int env, const EnvLoad &L, const bool with_keys = true,
+                                                const int lane_in = -1)
 {
-    const int lane = lane_id();
+    const int lane = lane_in >= 0 ? lane_in : lane_id();
     c.lane = lane;
     c.env = env;
     c.base = (size_t)env * S.cap;
@@ -237,10 +239,10 @@ __device__ __forceinline__ void load_env_commit(Ctx &c, const DevState &S, int e
     wave_sync();
 }
 
-__device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env, const bool with_keys = true)
+__device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env, const bool with_keys = true, const int lane_in = -1)
 {
-    const EnvLoad L = load_env_issue(S, env, with_keys);
-    load_env_commit(c, S, env, L, with_keys);
+    const EnvLoad L = load_env_issue(S, env, with_keys, lane_in);
+    load_env_commit(c, S, env, L, with_keys, lane_in);
 }
 
 // the candidate keys and stamps of a ring staged without them (load_env(.., false)), before an extraction
@@ -1884,10 +1886,14 @@ struct GroupArgs {
     int auto_reset;
 };
 
-__device__ __forceinline__ StepOuts late_outs()
+// tstep / n: the T-steps-per-launch closed loop (csrc/meshenv_fused.h) writes step t of the launch into slice t of
+// [T][n]-shaped output histories; every other kernel passes the literal 0 and compiles to what it was.
+typedef const __attribute__((address_space(4))) char *KernArgPtr;
+__device__ __forceinline__ StepOuts late_outs(const int tstep = 0, const int n_envs = 0, KernArgPtr ka_in = nullptr)
 {
     typedef const __attribute__((address_space(4))) char *kptr;
-    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    // (ka_in: a callee has no kernarg pointer of its own -- the out-of-line step of the T-step kernel gets it handed down)
+    kptr ka = ka_in ? ka_in : (kptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ka));  // not before this point
     typedef const __attribute__((address_space(4))) unsigned long long *qptr;
     qptr q = (qptr)(ka + offsetof(GroupArgs, outs));
@@ -1898,6 +1904,14 @@ __device__ __forceinline__ StepOuts late_outs()
     o.done = (uint8_t *)q[2];
     o.complete = (uint8_t *)q[3];
     o.term_obs = (float *)q[4];
+    if (tstep != 0) {
+        const size_t off = (size_t)tstep * (size_t)n_envs;
+        o.obs_out += off * kObsDim;
+        o.reward += off;
+        o.done += off;
+        o.complete += off;
+        if (o.term_obs) o.term_obs += off * kObsDim;
+    }
     return o;
 }
 
@@ -1906,11 +1920,12 @@ __device__ __forceinline__ StepOuts late_outs()
 // an auto-reset waits for it before it overwrites the ring)
 __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, const Decision &d, const EnvCounters &cnt0,
                                                  int n_before, int auto_reset, unsigned long long step0,
-                                                 volatile int *helper_done = nullptr, float *actor_row = nullptr)
+                                                 volatile int *helper_done = nullptr, float *actor_row = nullptr, const int tstep = 0,
+                                                 KernArgPtr ka = nullptr)
 {
     const StepResult r = env_finish(c, S.prm, d);
     const int env = c.env;
-    const StepOuts o = late_outs();
+    const StepOuts o = late_outs(tstep, S.n_envs, ka);
     float *__restrict__ obs_out = o.obs_out;
     double *__restrict__ reward = o.reward;
     uint8_t *__restrict__ done = o.done;
@@ -1962,14 +1977,17 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, cons
 // (the body as a function: k_step_group is just this; k_step_group_actor, csrc/meshenv_fused.h, appends the policy's forward)
 // (actor_in: k_step_group_actor only -- LDS [G][132] floats, the actor's first-layer input; nullptr otherwise)
 template <int G, bool kDefaultParams>
-__device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor_in = nullptr)
+__device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor_in = nullptr, const int tstep = 0,
+                                                KernArgPtr ka = nullptr, const int tid_in = -1)
 {
+    // (tid_in: the T-step kernel's per-iteration opaque thread id, so that nothing derived from it is hoisted out of its loop)
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;
     extern __shared__ double2 smem[];
     DevState S = A.S;
     const int cap = A.cap, auto_reset = A.auto_reset;
     const float *__restrict__ actions = A.actions;
     if (kDefaultParams) apply_default_params(S.prm);
-    const int wave = uniform_i32((int)(threadIdx.x >> 6));  // wave-uniform by construction: keeps env and every address derived from it in SGPRs
+    const int wave = uniform_i32(tid >> 6);  // wave-uniform by construction: keeps env and every address derived from it in SGPRs
     const size_t env_bytes = lds_bytes_for(cap);
     Handoff *ho = (Handoff *)((char *)smem + (size_t)G * env_bytes);
     const int env = blockIdx.x * G + wave;
@@ -1987,11 +2005,11 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
         const float *a = actions + (size_t)env * 3;
         const float a0 = a[0], a1 = a[1], a2 = a[2];
         const EnvCounters cnt0 = S.cnt[env];
-        load_env(c, S, env);
+        load_env(c, S, env, true, tid_in >= 0 ? (tid & 63) : -1);
         const int n_before = c.n;
         Decision d = env_check(c, S, a0, a1, a2, false);
         if (!d.ok) {
-            finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0, nullptr, actor_in ? actor_in + wave * 132 : nullptr);
+            finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0, nullptr, actor_in ? actor_in + wave * 132 : nullptr, tstep, ka);
         } else {
             pending = 1;
             if (c.lane == 0) {
@@ -2006,7 +2024,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
             }
         }
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((tid & 63) == 0) {
         ho[wave].valid = pending;
         ho[wave].simd = (int)__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11));  // HW_REG_HW_ID.simd_id
     }
@@ -2016,7 +2034,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     __syncthreads();
 #ifdef MESHENV_STAMPS
     const unsigned long long dbg_t2 = __builtin_amdgcn_s_memrealtime();
-    if (active && (threadIdx.x & 63) == 0) {
+    if (active && (tid & 63) == 0) {
         unsigned long long *o = S.dbg + (size_t)env * 16;
         o[0] = dbg_t0; o[1] = dbg_t1; o[2] = dbg_t2; o[3] = (unsigned long long)pending; o[4] = 0; o[5] = 0;
         if (!pending) o[15] = 0;
@@ -2024,7 +2042,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
 #endif
 
     // ---- deal the pending updates over the SIMDs (lane w reads wave w's entry: five ballots, not a 16-step loop)
-    const int dl = threadIdx.x & 63;
+    const int dl = tid & 63;
     int hv = 0, hs = -1;
     if (dl < G) {
         hv = ho[dl].valid;
@@ -2086,7 +2104,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
         Ctx c;
         carve_lds(c, (char *)smem + (size_t)hsrc * env_bytes, cap);
         Handoff &h = ho[hsrc];
-        c.lane = threadIdx.x & 63;
+        c.lane = tid & 63;
         Decision d = h.d;
         d.index = uniform_i32(d.index); d.new_vertex = uniform_i32(d.new_vertex);
         d.t0 = uniform_i32(d.t0); d.t1 = uniform_i32(d.t1);
@@ -2100,7 +2118,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
         }
         if (c.lane == 0) {
             *(volatile int *)&h.helper_done = 1;
-            const StepOuts o = late_outs();
+            const StepOuts o = late_outs(tstep, S.n_envs, ka);
             o.reward[henv] = rew;
             if (S.msg) S.msg[(size_t)henv * 21 + 18] = (float)rew;
         }
@@ -2111,7 +2129,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     Ctx c;
     carve_lds(c, (char *)smem + (size_t)src * env_bytes, cap);
     Handoff &h = ho[src];
-    c.lane = threadIdx.x & 63;
+    c.lane = tid & 63;
     c.env = uniform_i32(h.env);
     c.base = (size_t)c.env * S.cap;
     c.n = uniform_i32(h.n); c.ref = uniform_i32(h.ref); c.n_elem = uniform_i32(h.n_elem); c.failed = uniform_i32(h.failed);
@@ -2132,7 +2150,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     const unsigned long long dbg_t8 = __builtin_amdgcn_s_memrealtime();
 #endif
     finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0, helpers ? &h.helper_done : nullptr,
-                     actor_in ? actor_in + src * 132 : nullptr);
+                     actor_in ? actor_in + src * 132 : nullptr, tstep, ka);
 #ifdef MESHENV_STAMPS
     if (c.lane == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();

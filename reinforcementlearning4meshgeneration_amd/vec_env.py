@@ -473,6 +473,41 @@ class MeshVecEnv:
         self._check(rc, "meshenv_step_actor")
         return self.obs, self.reward, self.done, self.complete, nxt
 
+    def step_actor_T(self, actor, actions0, T: int, seed: int = 0, counter: int = 0, sample: bool = True,
+                     want_terminal_obs: bool = False, want_eps: bool = False):
+        """T vector steps of the closed loop (env step + policy) in ONE launch where the batch runs on the fused CU-group
+        kernel (meshenv_step_actor_multi; T x step_actor otherwise, identical results).  actions0: [n, 3] actions of the first
+        step.  Returns a dict of histories: actions [T+1, n, 3] (slice t + 1 = the policy's answer to the observations of
+        step t; pass actions[T] as the next call's actions0), obs [T, n, 18], reward [T, n], done [T, n], complete [T, n],
+        and terminal_obs [T, n, 18] / eps [T, n, 3] when asked for.  The noise counter of step t is counter + t."""
+        t = self._torch
+        n = self.num_envs
+        T = int(T)
+        acts = t.empty((T + 1, n, 3), dtype=t.float32, device=self.device)
+        acts[0].copy_(actions0.to(device=self.device, dtype=t.float32).reshape(n, 3))
+        out = dict(actions=acts, obs=t.empty((T, n, _capi.OBS_DIM), dtype=t.float32, device=self.device),
+                   reward=t.empty((T, n), dtype=t.float64, device=self.device),
+                   done=t.empty((T, n), dtype=t.uint8, device=self.device),
+                   complete=t.empty((T, n), dtype=t.uint8, device=self.device))
+        if want_terminal_obs:
+            out["terminal_obs"] = t.zeros((T, n, _capi.OBS_DIM), dtype=t.float32, device=self.device)
+        if want_eps:
+            out["eps"] = t.empty((T, n, 3), dtype=t.float32, device=self.device)
+        self._bind_stream()
+        stream = t.cuda.current_stream(self.device).cuda_stream
+        if stream != actor._stream:
+            actor._L.meshenv_actor_set_stream(actor._h, C.c_void_p(stream))
+            actor._stream = stream
+        rc = self._L.meshenv_step_actor_multi(self._handle, actor._h, T, acts.data_ptr(), out["obs"].data_ptr(), out["reward"].data_ptr(),
+                                          out["done"].data_ptr(), out["complete"].data_ptr(),
+                                          out["terminal_obs"].data_ptr() if want_terminal_obs else None,
+                                          1 if self.auto_reset else 0, 1 if sample else 0, C.c_uint64(seed & (2 ** 64 - 1)),
+                                          C.c_uint64(counter & (2 ** 64 - 1)), out["eps"].data_ptr() if want_eps else None)
+        self._check(rc, "meshenv_step_actor_multi")
+        self.obs.copy_(out["obs"][T - 1])      # the env's current observation / flags, as after T single steps
+        self.reward.copy_(out["reward"][T - 1]); self.done.copy_(out["done"][T - 1]); self.complete.copy_(out["complete"][T - 1])
+        return out
+
     def rollout(self, actions):
         """T consecutive steps in one kernel launch.  actions: float32 CUDA tensor [T, n, 3].
         Returns (obs_after_last_step [n,18], reward [T,n], done [T,n], complete [T,n])."""

@@ -115,3 +115,57 @@ def test_fused_step_and_actor_equals_the_two_launch_path():
         assert a_env.counters() == b_env.counters() and a_env.counters()["valid"] > 0.02 * n * 96
         a_env.close(); b_env.close()
     actor.close()
+
+
+def test_t_steps_per_launch_equals_single_step_launches():
+    """meshenv_step_actor_multi: T vector steps of the closed loop (env step + SAC actor) in ONE launch -- every workgroup loops
+    over its own 16 envs -- against T calls of meshenv_step_actor on a second, identical batch: every slice of the
+    observation / reward / flag / terminal-observation / noise histories and of the action history bit-identical, work
+    counters equal; 4096 d1 envs (the fused kernel) over 4 x 24 steps, 4096 boundary() envs, and the step-by-step fallback
+    (2048 envs: not the CU-group size)."""
+    import os
+    import torch
+    from conftest import GOLDEN_DIR
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv, boundary
+    from reinforcementlearning4meshgeneration_amd.actor import FusedActor
+    torch.manual_seed(11)
+    lin = [torch.nn.Linear(18, 128), torch.nn.Linear(128, 128), torch.nn.Linear(128, 128)]
+    mu, ls = torch.nn.Linear(128, 3), torch.nn.Linear(128, 3)
+    with torch.no_grad():
+        mu.weight.mul_(6.0)
+        ls.bias.fill_(-0.5)
+    actor = FusedActor.from_torch(lin, mu, ls)
+    d1 = [tuple(p) for p in np.load(os.path.join(GOLDEN_DIR, "boundary16_biased_s2.npz"))["domain_xy"]]
+    for dom, n, T, chunks in ((d1, 4096, 24, 4), (boundary(0), 4096, 7, 6), (d1, 2048, 5, 2)):
+        a_env = MeshVecEnv([dom], n_envs=n)
+        b_env = MeshVecEnv([dom], n_envs=n)
+        a_env.reset(); b_env.reset()
+        act_a = actor.sample(a_env.obs, seed=5, counter=0).clone()
+        act_b = act_a.clone()
+        for k in range(chunks):
+            c0 = 1 + k * T
+            singles = dict(obs=[], reward=[], done=[], complete=[], actions=[act_a.clone()], term=[], eps=[])
+            for t in range(T):
+                eps = torch.empty((n, 3), device="cuda")
+                a_env.terminal_obs.zero_()
+                o, r, d, c, nxt = a_env.step_actor(actor, act_a, seed=5, counter=c0 + t, eps_out=eps)
+                singles["obs"].append(o.clone()); singles["reward"].append(r.clone()); singles["done"].append(d.clone())
+                singles["complete"].append(c.clone()); singles["actions"].append(nxt.clone()); singles["eps"].append(eps)
+                singles["term"].append(a_env.terminal_obs.clone())
+                act_a = nxt.clone()
+            h = b_env.step_actor_T(actor, act_b, T, seed=5, counter=c0, want_terminal_obs=True, want_eps=True)
+            for t in range(T):
+                assert torch.equal(h["obs"][t], singles["obs"][t]) and torch.equal(h["reward"][t], singles["reward"][t]), (n, k, t)
+                assert torch.equal(h["done"][t], singles["done"][t]) and torch.equal(h["complete"][t], singles["complete"][t]), (n, k, t)
+                assert torch.equal(h["actions"][t + 1], singles["actions"][t + 1]) and torch.equal(h["eps"][t], singles["eps"][t]), (n, k, t)
+                dn = singles["done"][t].bool()
+                assert torch.equal(h["terminal_obs"][t][dn], singles["term"][t][dn]), (n, k, t)
+            assert torch.equal(h["actions"][0], singles["actions"][0])
+            act_b = h["actions"][T].clone()
+            assert torch.equal(b_env.obs, a_env.obs)
+        assert a_env.counters() == b_env.counters() and a_env.counters()["valid"] > 0.02 * n * T * chunks
+        for e in range(0, n, 257):
+            sa, sb = a_env.get_state(e), b_env.get_state(e)
+            assert np.array_equal(sa["ring_ids"], sb["ring_ids"]) and np.array_equal(sa["ring_xy"], sb["ring_xy"]) and sa["ref_id"] == sb["ref_id"]
+        a_env.close(); b_env.close()
+    actor.close()
