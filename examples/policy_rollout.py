@@ -143,7 +143,16 @@ def main():
                       "env_steps_per_s": steps / dt, "us_per_vector_step": 1e6 * dt / args.steps,
                       "valid_action_rate": (c1["valid"] - c0["valid"]) / steps,
                       "episodes_finished_per_1000_env_steps": 1000.0 * ep_done / (50 * args.envs),
-                      "completed_fraction": ep_complete / max(1, ep_done), "mean_reward": rew_sum / (50 * args.envs)}))
+                      "completed_fraction": ep_complete / max(1, ep_done), "mean_reward": rew_sum / (50 * args.envs),
+                      # for tools/profile_set.sh: algorithmic bytes per launch of the kernels of this loop (SURVEY 8d's step
+                      # formula from the work counters; the actor reads 72 B and writes 12 B per env + its 141 KB of weights)
+                      "profile_kernels": [
+                          {"match": "k_step_group", "algorithmic_bytes_per_launch":
+                              (28 * (c1["sum_ring"] - c0["sum_ring"]) + 158 * steps + 28 * (c1["sum_ring_valid"] - c0["sum_ring_valid"])
+                               + 48 * (c1["valid"] - c0["valid"])) / args.steps + (84.0 * args.envs + 141e3 if args.actor in ("one-launch", "t-steps") else 0.0),
+                           "note": "env step (28 sum_n + 158 steps + 28 sum_n_valid + 48 valid) per vector step; the one-launch kernel adds the actor's 84 B per env + weights"},
+                          {"match": "k_actor_forward", "algorithmic_bytes_per_launch": 84.0 * args.envs + 141e3,
+                           "note": "18 f32 observations in, 3 f32 actions out per env, 35 k f32 weights once"}]}))
     env.close()
 
 

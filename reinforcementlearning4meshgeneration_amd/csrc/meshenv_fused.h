@@ -67,7 +67,7 @@ struct GroupActorArgsT {
 };
 
 #ifndef MESHENV_T_ALL3
-#define MESHENV_T_ALL3 false   // all three layers' weights requested ahead do not fit next to the loop's live values: they spill
+#define MESHENV_T_ALL3 true    // (false: 117 spilled VGPRs instead of 77; the hardware thread id for the actor: 147 -- its weight loads are hoisted)
 #endif
 template <bool kDefaultParams>
 __global__ void __launch_bounds__(64 * 16)
@@ -102,8 +102,7 @@ k_step_group_actor_T(GroupActorArgsT A)
         const aptr Bp = (aptr)ka;
         const ActorWeights W = Bp->W;
         ActorHead hd;
-        // (the actor gets the hardware thread id: its wave index must stay provably wave-uniform -- scalar weight addresses)
-        actor_request_weights(hd, W, threadIdx.x, MESHENV_T_ALL3);
+        actor_request_weights(hd, W, tid, MESHENV_T_ALL3);
         if (dbg && tid == 0) dbg[((size_t)blockIdx.x * T + tt) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
         __syncthreads();
         if (dbg && tid == 0) dbg[((size_t)blockIdx.x * T + tt) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
@@ -111,7 +110,7 @@ k_step_group_actor_T(GroupActorArgsT A)
         float *eps = Bp->eps_out;
         actor_forward_tile(W, hd, (int)n, blockIdx.x * kActEnvs, nullptr, nullptr, const_cast<float *>(Bp->g.actions) + (size_t)(tt + 1) * n * 3,
                            Bp->sample, Bp->seed, Bp->counter + (unsigned long long)tt, eps ? eps + (size_t)tt * n * 3 : nullptr, lds,
-                           threadIdx.x, 64 * 16);
+                           tid, 64 * 16);
         __syncthreads();   // the actions of step t + 1 and the environments' state are written: visible to the whole workgroup
         if (dbg && tid == 0) dbg[((size_t)blockIdx.x * T + tt) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }

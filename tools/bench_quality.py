@@ -42,7 +42,11 @@ for mode in (True, False):
         le = env.get_last_episode(int(k)); nv += len(np.unique(le["quads"]))
     nv = nv / 64 * n
     by = ne * (16 + (64 if mode else 0)) + nv * 16 + n * (64 + 16 + 256 + 4)
+    by_modes = dict(globals().get("by_modes", {})); by_modes[mode] = by
     print(f"records={'on' if mode else 'off'}: {ms*1e3:.1f} us/launch, {ne} elements ({ne/n:.1f}/env), "
           f"{ne/ms/1e6:.2f} G elements/s, algorithmic {by/1e6:.1f} MB -> {by/ms/1e6:.0f} GB/s = {by/ms/1e6/8000*100:.1f}% of 8 TB/s")
+import json
+print(json.dumps({"profile_kernels": [{"match": "k_element_quality", "algorithmic_bytes_per_launch": float(0.5 * (by_modes[True] + by_modes[False])),
+                                       "note": f"{n} archived meshes, {ne} elements: 16 B ids (+ 64 B record) per element, 16 B per referenced vertex, 340 B per env; half of the profiled launches write the per-element records, half do not: the figure is their mean"}]}))
 rep = env.quality_report("last")
 print({k: (round(v["average"], 4), round(v["std"], 4)) for k, v in rep.items() if isinstance(v, dict)})

@@ -114,3 +114,10 @@ for k in np.nonzero(finished[:shadow])[0]:
 dt = time.perf_counter() - t0
 print(f"oracle (1 thread): {dt / max(cnt, 1) * 1e6:.1f} us/mesh -> {dt / max(cnt, 1) * nfin * 1e3:.1f} ms for {nfin}; "
       f"device/oracle speed {dt / max(cnt, 1) * nfin * 1e3 / ms:.0f}x")
+
+import json
+print(json.dumps({"profile_kernels": [
+    {"match": "k_smooth_interior", "algorithmic_bytes_per_launch": float(n) * 1600.0, "note": "record 64 + domain ring 16 n0 + element log 16 n_elem + generated vertices 16 n_new in and out + front ids 4 n ~ 1.6 KB per env (DESIGN section 7)"},
+    {"match": "k_smooth_front", "algorithmic_bytes_per_launch": float(n) * 1600.0, "note": "same inputs as the interior pass"},
+    {"match": "k_rebuild_candidates", "algorithmic_bytes_per_launch": float(n) * (2 * 28 * 24 + 158 + 72), "note": "ring read and rewritten (28 B per slot, ~24 slots) + record + observation"},
+    {"match": "k_smooth_final", "algorithmic_bytes_per_launch": float(nfin) * 1400.0, "note": "finished meshes only: ring + logs in, vertices out"}]}))
