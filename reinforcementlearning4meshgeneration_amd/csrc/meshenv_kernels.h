@@ -676,32 +676,72 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
 
 // is_point_inside_area -> calculate_crossing_segments, M:539-546, 47-102.  One ring edge per lane, ballot parity.
 // Orientation tests only use sign and zero-ness of round(dy, 4), so the scaled roundings are used.
-__device__ __forceinline__ bool point_inside(const Ctx &c, const Params &prm, P2 p)
+__device__ __forceinline__ int nf_compact(Ctx &c, bool near, int i, int count);
+
+// one edge (ring[ic], ring[ic - 1]) of the crossing count: M:47-102 for that edge
+__device__ __forceinline__ bool edge_counted(const Ctx &c, P2 p, P2 far, int ic, bool in)
+{
+    const int n = c.n;
+    const int im1 = wrapi(ic - 1, n);
+    const P2 vi = ldp(c, ic), vm = ldp(c, im1);
+    const bool np_i = (c.id[ic] & kNewBit) != 0, np_m = (c.id[im1] & kNewBit) != 0;
+    const double dy = vi.y - vm.y;
+    const double orientation = (np_i || np_m) ? round4_np_scaled(dy) : round4_py_scaled(dy);
+    bool counted = false;
+    // is_cross is a pure conjunction; the ray-side test is the selective one, so it goes first
+    if (in && orientation != 0.0 && straddle(p, far, vi, vm) && straddle(vi, vm, p, far)) {
+        const bool on_i = round4_np_scaled(vi.y - p.y) == 0.0, on_m = round4_np_scaled(vm.y - p.y) == 0.0;
+        // neighbour edge: the next one when the ray passes through vertex i, the previous one when through i-1
+        const int ia = on_i ? wrapi(ic + 1, n) : im1, ib = on_i ? ic : wrapi(ic - 2, n);
+        const double dyo = ldp(c, ia).y - ldp(c, ib).y;
+        const double other = ((c.id[ia] & kNewBit) != 0 || (c.id[ib] & kNewBit) != 0) ? round4_np_scaled(dyo) : round4_py_scaled(dyo);
+        const bool keep = other != 0.0 && !(other * orientation < 0.0);
+        counted = on_i ? (keep && orientation < 0.0) : (on_m ? (keep && !(orientation < 0.0)) : true);
+    }
+    return counted;
+}
+
+__device__ __forceinline__ bool point_inside(Ctx &c, const Params &prm, P2 p)
 {
     const int n = c.n;
     const P2 far = mkp(prm.ray_length, p.y);
     int parity = 0;
+#if !defined(MESHENV_NO_FILTERS) && !defined(MESHENV_NO_PIP_FILTER)
+    if (n > 64) {
+        // Rings of several 64-vertex chunks: an exact pre-filter per edge, the survivors compacted (c.list), and the
+        // crossing test itself once over the survivors instead of once per chunk.  An edge whose endpoints lie strictly on
+        // the same side of the ray's line cannot be counted: with a = vi.y - p.y, b = vm.y - p.y of equal sign and
+        // |a| > 2e-3 |vi.x - p.x|, |b| > 2e-3 |vm.x - p.x| (and > 1e-9), both collinearity terms of
+        // straddle(p, far, vi, vm) fail sin_rounds_to_zero's first test (|c| > 1e-3 |d|: c = -a (L - p.x), d = dx (L - p.x))
+        // and its cross products -(L - p.x) a and -(L - p.x) b have the same sign and cannot underflow: straddle is False,
+        // is_cross is False, the edge adds nothing.  Identical results by construction (the filter only drops edges the full
+        // test rejects); -DMESHENV_NO_FILTERS / -DMESHENV_NO_PIP_FILTER build the unfiltered form.
+        int count = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + c.lane;
+            const bool in = i < n;
+            const int ic = in ? i : 0;
+            const P2 vi = ldp(c, ic), vm = ldp(c, wrapi(ic - 1, n));
+            const double a = vi.y - p.y, b = vm.y - p.y;
+            const double ma = fmax(2e-3 * fabs(vi.x - p.x), 1e-9), mb = fmax(2e-3 * fabs(vm.x - p.x), 1e-9);
+            const bool clear = (a > ma && b > mb) || (a < -ma && b < -mb);
+            count = nf_compact(c, in && !clear, i, count);
+        }
+        wave_sync();
+        for (int j0 = 0; j0 < count; j0 += 64) {
+            const int j = j0 + c.lane;
+            const bool in = j < count;
+            const int ic = c.list[in ? j : 0];
+            parity ^= __popcll(__ballot(edge_counted(c, p, far, ic, in))) & 1;
+        }
+        wave_sync();
+        return parity != 0;
+    }
+#endif
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + c.lane;
         const bool in = i < n;
-        const int ic = in ? i : 0;
-        const int im1 = wrapi(ic - 1, n);
-        const P2 vi = ldp(c, ic), vm = ldp(c, im1);
-        const bool np_i = (c.id[ic] & kNewBit) != 0, np_m = (c.id[im1] & kNewBit) != 0;
-        const double dy = vi.y - vm.y;
-        const double orientation = (np_i || np_m) ? round4_np_scaled(dy) : round4_py_scaled(dy);
-        bool counted = false;
-        // is_cross is a pure conjunction; the ray-side test is the selective one, so it goes first
-        if (in && orientation != 0.0 && straddle(p, far, vi, vm) && straddle(vi, vm, p, far)) {
-            const bool on_i = round4_np_scaled(vi.y - p.y) == 0.0, on_m = round4_np_scaled(vm.y - p.y) == 0.0;
-            // neighbour edge: the next one when the ray passes through vertex i, the previous one when through i-1
-            const int ia = on_i ? wrapi(ic + 1, n) : im1, ib = on_i ? ic : wrapi(ic - 2, n);
-            const double dyo = ldp(c, ia).y - ldp(c, ib).y;
-            const double other = ((c.id[ia] & kNewBit) != 0 || (c.id[ib] & kNewBit) != 0) ? round4_np_scaled(dyo) : round4_py_scaled(dyo);
-            const bool keep = other != 0.0 && !(other * orientation < 0.0);
-            counted = on_i ? (keep && orientation < 0.0) : (on_m ? (keep && !(orientation < 0.0)) : true);
-        }
-        parity ^= __popcll(__ballot(counted)) & 1;
+        parity ^= __popcll(__ballot(edge_counted(c, p, far, in ? i : 0, in))) & 1;
     }
     return parity != 0;
 }
