@@ -126,7 +126,8 @@ int meshenv_create_random(int device, int n_envs, uint64_t seed0, int num_verts,
  * density the value every generated vertex carries.  Where the reference raises ZeroDivisionError -- an edge of 0.5 - 1.5
  * spacings gets round(...) == 0 interior points and (B - A) / 0 -- no environment can be built:
  *   seeds_host   [n_envs] nullable: the seed of every ring (NULL: seed0 + k), so that a caller can leave those seeds out
- *   raises_host  [n_envs] nullable: 1 where calculate_density raises for that ring
+ *   raises_host  [n_envs] nullable: 1 where calculate_density raises for that ring; 2 where the polygon itself is not
+ *                generated on the device (fewer than 5 distinct pixels: the host function would draw another one)
  *   out          nullable: NULL = probe only (fills raises_host, builds nothing)
  * Returns MESHENV_E_STATE, *out = NULL and raises_host filled if any ring raises (MeshVecEnv.from_random_density probes a
  * seed range first and then passes the seeds that are defined).  cos / sin of the edge directions come from the host
@@ -449,6 +450,26 @@ int meshenv_actor_sample(MeshActor *a, int n, const float *obs_dev, uint64_t see
 int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float *obs_dev, double *reward_dev, uint8_t *done_dev,
                        uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset, int sample, uint64_t seed, uint64_t counter,
                        float *actions_next_dev, float *eps_out_dev);
+
+/*
+ * MeshGeneration.extract_samples_2(meshes, n_neighbor, n_radius, radius, index, quality_threshold), general/mesh.py:1438-1489
+ * (the data-preparation step of the ANN scripts: general/EBRD.py:414, 579 with (2, 3, radius 4, index 1) and
+ * general/post_processing.py:532 with (3, 3, radius 6, index 5)) for the generated mesh of EVERY env in one launch
+ * (csrc/meshenv_samples.h): which = 0 the running episode's elements, 1 the archived (finished) episode.  Needs
+ * log_capacity > 0.  Two calls:
+ *   1. offsets_dev = NULL: count_dev [n_envs] int64 = samples of every env, status_dev [n_envs] uint8 (0 ok, 1 masked out,
+ *      2 log overflow, 3 a vertex with more than 16 neighbours, 4 more than 32 close vertices in a sector: count 0);
+ *   2. offsets_dev [n_envs + 1] int64 = where env k's samples start / end (the exclusive prefix sum of the counts; count_dev
+ *      and status_dev as the first call left them), samples_dev
+ *      [total][2 * (2 n_neighbor + n_radius)], outputs_dev [total][2], types_dev [total] float64: the three lists the
+ *      reference returns, env after env, in the reference's order (element, corner, right path, sector tuple, left path).
+ * Values: bit-identical to the reference's except the entries of the synthetic sector points, whose coordinates pass
+ * through cos / sin of an unquantised angle (<= 2 ulp); reinforcementlearning4meshgeneration_amd.samples is the host
+ * restatement (tests/test_gpu_samples.py, tests/test_samples_cpu.py).
+ */
+int meshenv_extract_samples(MeshEnv *h, int which, const uint8_t *mask_dev, int n_neighbor, int n_radius, double radius, int index,
+                            double quality_threshold, int64_t *count_dev, uint8_t *status_dev, const int64_t *offsets_dev,
+                            double *samples_dev, double *outputs_dev, double *types_dev);
 
 /* T vector steps of the closed loop in ONE launch (csrc/meshenv_fused.h, k_step_group_actor_T): the workgroups of the
  * fused kernel never talk to each other, so each loops [step its 16 envs -> actor forward] T times on its own -- one launch

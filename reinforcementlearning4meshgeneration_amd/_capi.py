@@ -45,7 +45,7 @@ EXPORTS = [
     "meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid", "meshenv_step_kernel",
     "meshenv_create_random", "meshenv_get_domain", "meshenv_smooth", "meshenv_smooth_final", "meshenv_get_not_valid_ids", "meshenv_step_actor",
     "meshenv_libm_exact", "meshenv_create_random_density", "meshenv_density_rings",
-    "meshenv_step_actor_multi",
+    "meshenv_step_actor_multi", "meshenv_extract_samples",
 ]
 
 
@@ -114,6 +114,8 @@ def load():
     L.meshenv_step_actor.restype = C.c_int
     L.meshenv_step_actor_multi.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_uint64, C.c_uint64, vp]
     L.meshenv_step_actor_multi.restype = C.c_int
+    L.meshenv_extract_samples.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, vp, vp, vp, vp, vp, vp]
+    L.meshenv_extract_samples.restype = C.c_int
     L.meshenv_smooth.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.meshenv_smooth.restype = C.c_int
     L.meshenv_smooth_final.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, C.c_double, vp, vp]

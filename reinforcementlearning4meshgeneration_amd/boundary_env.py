@@ -154,11 +154,13 @@ class BoudaryEnv:  # the reference's spelling
 
     def extract_samples_2(self, meshes=None, n_neighbor=2, n_radius=3, radius=4, index=1, quality_threshold=0.7):
         """MeshGeneration.extract_samples_2, general/mesh.py:1438-1489, on this env's generated mesh (`meshes` is implied:
-        the elements of the running episode).  Host-side like the reference's; see samples.py."""
-        from .samples import extract_samples_2
-        quads, vxy = self._vec.get_elements(0)
-        return extract_samples_2(quads, vxy, len(self.points), n_neighbor, n_radius, radius, index=index,
-                                 quality_threshold=quality_threshold)
+        the elements of the running episode), computed on the device (meshenv_extract_samples).  Returns the reference's
+        three lists: all_samples (rows of 2 (2 n_neighbor + n_radius) floats), types ([1] / [0] / [0.5]), outputs."""
+        samples, types, outputs, _, status = self._vec.extract_samples(n_neighbor, n_radius, float(radius), index, quality_threshold)
+        if int(status.cpu()[0]) != 0:
+            raise RuntimeError(f"extract_samples_2(): not applicable to this episode (status {int(status.cpu()[0])}: log overflow / "
+                               "vertex degree / sector size, see include/meshenv.h)")
+        return samples.cpu().tolist(), [[t] for t in types.cpu().tolist()], outputs.cpu().tolist()
 
     @property
     def not_valid_points(self):

@@ -290,7 +290,7 @@ __device__ __forceinline__ int gen_ring(GenScratch *g, const GenParams &P, unsig
     {
         const int n_rand = nv + 1 + 2 * ((nv + 1) / 2);
         if (pos + 2 * n_rand > kMtN) {
-            if (lane == 0) atomicOr(err, 1);
+            if (lane == 0) { if (P.raises) P.raises[ring_index] = 2; else atomicOr(err, 1); }
             return 0;
         }
         // ---- generatePolygon
@@ -353,8 +353,8 @@ __device__ __forceinline__ int gen_ring(GenScratch *g, const GenParams &P, unsig
         // random_polygon_px() draws another polygon from the same stream when fewer than 5 distinct vertices remain (with
         // numVerts >= 8 that needs four coincident pixels in a row); gauss() carries its cached half over to that draw, which
         // is not restated here: the ring is reported as failed instead, loudly
-        if (cnt < 5) {
-            if (lane == 0) atomicOr(err, 1);
+        if (cnt < 5) {   // (density mode with a flag array: flagged 2 = "not generated here", the caller leaves the seed out)
+            if (lane == 0) { if (P.raises) P.raises[ring_index] = 2; else atomicOr(err, 1); }
             return 0;
         }
         n_ring = cnt;

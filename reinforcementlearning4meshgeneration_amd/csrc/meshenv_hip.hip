@@ -19,6 +19,7 @@
 #include "meshenv_kernels.h"
 #include "meshenv_quality.h"
 #include "meshenv_smooth.h"
+#include "meshenv_samples.h"
 #include "meshenv_fused.h"
 
 using namespace meshenv;
@@ -57,6 +58,7 @@ struct MeshEnv {
     bool smooth_final_ready = false;
     bool fused_ready = false;          // k_step_group_actor's LDS attribute set
     bool fused_T_ready = false;        // k_step_group_actor_T's
+    bool samples_ready = false;        // k_extract_samples' LDS attribute set
     // move() API state, allocated by the first meshenv_move: not_valid_points per env
     double2 *nv_xy = nullptr;    // [E][cap]
     int32_t *nv_count = nullptr; // [E]
@@ -1585,6 +1587,45 @@ int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float
     hipLaunchKernelGGL((k_step_group_actor<true>), dim3((h->n_envs + 15) / 16), dim3(64 * 16), group_actor_lds_bytes(h->cap), h->stream, GA);
     HIP_TRY(h, hipGetLastError());
     h->steps_done += 1;
+    return MESHENV_OK;
+}
+
+int meshenv_extract_samples(MeshEnv *h, int which, const uint8_t *mask_dev, int n_neighbor, int n_radius, double radius, int index,
+                            double quality_threshold, int64_t *count_dev, uint8_t *status_dev, const int64_t *offsets_dev,
+                            double *samples_dev, double *outputs_dev, double *types_dev)
+{
+    if (!h || (which != 0 && which != 1) || !count_dev || !status_dev) return MESHENV_E_ARG;
+    if (n_neighbor < 1 || n_neighbor > kSampMaxNeighbor || n_radius < 1 || n_radius > kSampMaxRadius || !(radius > 0) ||
+        (index != 1 && index != 5))
+        return fail_arg(h, "meshenv_extract_samples: n_neighbor in 1..3, n_radius in 1..4, radius > 0 and index 1 or 5 (the values of the reference's callers) are supported");
+    if (offsets_dev && (!samples_dev || !outputs_dev || !types_dev))
+        return fail_arg(h, "meshenv_extract_samples: offsets_dev given without the three output arrays");
+    const int log_cap = h->S.prm.log_cap;
+    if (log_cap <= 0) {
+        h->err = "meshenv_extract_samples: handle was created with log_capacity = 0 (the mesh graph is rebuilt from the element log)";
+        return MESHENV_E_STATE;
+    }
+    const size_t lds = samples_lds_bytes(h->cap, log_cap);
+    if (lds > 160 * 1024 || h->cap + log_cap > 65535)
+        return fail_arg(h, "meshenv_extract_samples: ring stride + log_capacity too large for the kernel's LDS (49 B per vertex)");
+    MESHENV_ON_DEVICE(h);
+    int rc = ensure_libm_tables(h);
+    if (rc != MESHENV_OK) return rc;
+    if (!h->samples_ready) {
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_extract_samples<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_extract_samples<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        h->samples_ready = true;
+    }
+    SampleParams P;
+    P.n_neighbor = n_neighbor; P.n_radius = n_radius; P.index = index; P.radius = radius; P.quality_threshold = quality_threshold;
+    const dim3 grid(h->n_envs), block(64);
+    if (!offsets_dev)
+        hipLaunchKernelGGL(k_extract_samples<false>, grid, block, lds, h->stream, h->S, h->cap, which, mask_dev, P, libm_ref(h),
+                           (long long *)count_dev, status_dev, (const long long *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+    else
+        hipLaunchKernelGGL(k_extract_samples<true>, grid, block, lds, h->stream, h->S, h->cap, which, mask_dev, P, libm_ref(h),
+                           (long long *)count_dev, status_dev, (const long long *)offsets_dev, samples_dev, outputs_dev, types_dev);
+    HIP_TRY(h, hipGetLastError());
     return MESHENV_OK;
 }
 

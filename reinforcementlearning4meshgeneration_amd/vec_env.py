@@ -508,6 +508,40 @@ class MeshVecEnv:
         self.reward.copy_(out["reward"][T - 1]); self.done.copy_(out["done"][T - 1]); self.complete.copy_(out["complete"][T - 1])
         return out
 
+    def extract_samples(self, n_neighbor: int = 2, n_radius: int = 3, radius: float = 4.0, index: int = 1,
+                        quality_threshold: float = 0.7, which: str = "current", mask=None):
+        """MeshGeneration.extract_samples_2 (general/mesh.py:1438-1489) for the generated mesh of every env, on the device
+        (meshenv_extract_samples: a counting launch, a prefix sum, a filling launch).  Returns (samples [total, 2 (2 n_neighbor +
+        n_radius)], types [total], outputs [total, 2], offsets [n + 1] int64, status [n] uint8) as CUDA tensors: env k's
+        samples are rows offsets[k] .. offsets[k + 1], in the reference's order."""
+        if which not in ("current", "last"):
+            raise ValueError("which must be 'current' or 'last'")
+        t = self._torch
+        n = self.num_envs
+        cnt = t.zeros(n, dtype=t.int64, device=self.device)
+        st = t.zeros(n, dtype=t.uint8, device=self.device)
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=t.uint8).contiguous()
+            mptr = mask.data_ptr()
+        self._bind_stream()
+        w = 1 if which == "last" else 0
+        args = (int(n_neighbor), int(n_radius), float(radius), int(index), float(quality_threshold))
+        self._check(self._L.meshenv_extract_samples(self._handle, w, mptr, *args, cnt.data_ptr(), st.data_ptr(), None, None, None, None),
+                    "meshenv_extract_samples")
+        offs = t.zeros(n + 1, dtype=t.int64, device=self.device)
+        offs[1:] = t.cumsum(cnt, 0)
+        total = int(offs[-1].item())
+        row = 2 * (2 * int(n_neighbor) + int(n_radius))
+        samples = t.empty((max(total, 1), row), dtype=t.float64, device=self.device)
+        outputs = t.empty((max(total, 1), 2), dtype=t.float64, device=self.device)
+        types = t.empty(max(total, 1), dtype=t.float64, device=self.device)
+        if total:
+            self._check(self._L.meshenv_extract_samples(self._handle, w, mptr, *args, cnt.data_ptr(), st.data_ptr(), offs.data_ptr(),
+                                                        samples.data_ptr(), outputs.data_ptr(), types.data_ptr()),
+                        "meshenv_extract_samples")
+        return samples[:total], types[:total], outputs[:total], offs, st
+
     def rollout(self, actions):
         """T consecutive steps in one kernel launch.  actions: float32 CUDA tensor [T, n, 3].
         Returns (obs_after_last_step [n,18], reward [T,n], done [T,n], complete [T,n])."""

@@ -1,8 +1,10 @@
-"""Training-set extraction from a generated mesh: MeshGeneration.extract_samples_2 (general/mesh.py:1438-1489), the
-data-preparation step of the reference's ANN scripts (general/EBRD.py:414,579, general/post_processing.py:532).
+"""TEST INFRASTRUCTURE: host restatement of MeshGeneration.extract_samples_2 (general/mesh.py:1438-1489), the
+data-preparation step of the reference's ANN scripts (general/EBRD.py:414,579, general/post_processing.py:532).  The
+product path is the device kernel (csrc/meshenv_samples.h, meshenv_extract_samples); this module is what the tests
+compare it with on arbitrary meshes, and is itself pinned on the lists the reference returned
+(tests/test_samples_cpu.py, tests/golden/samples_*.npz).
 
-Host-side Python like the reference's (a combinatorial walk over one mesh with a variable-length result -- no device
-work): it consumes what the device produces, `MeshVecEnv.get_elements(env)` / `get_last_episode(env)` (elements as global
+It consumes what the device produces, `MeshVecEnv.get_elements(env)` / `get_last_episode(env)` (elements as global
 vertex ids, the vertex table, domain ring first), and rebuilds the `Vertex.segments` neighbour lists the way
 `csrc/meshenv_smooth.h` does: the domain ring's own segments (general/mesh.py:1926-1930), then Mesh.connect_vertices
 (general/components.py:832-837) of every element in order.
@@ -82,18 +84,30 @@ def element_quality(p: Sequence[Point], index: int) -> float:
     raise NotImplementedError("extract_samples_2 is called with index 1 or 5 in the reference")
 
 
-def _get_nodes(adj, root: int, exclusion: Sequence[int], layer: int, path: List[int], paths: List[List[int]], N: int):
-    """general/mesh.py:1422-1436: depth-first neighbour paths of N vertices; `path` is shared and overwritten in place."""
-    if len(path) < N:
-        path.append(root)
-    else:
-        path[-layer - 1] = root
-    if layer == 0:
-        paths.append(list(path))
-        return
-    nodes = [v for v in adj[root] if v not in exclusion and v not in path[:N - layer]]
-    for v in nodes:
-        _get_nodes(adj, v, exclusion, layer - 1, path, paths, N)
+def neighbour_paths(adj, root: int, excluded: Sequence[int], N: int) -> List[List[int]]:
+    """The paths of N vertices that MeshGeneration.get_nodes (general/mesh.py:1422-1436) emits from `root`, in its order,
+    written as plain loops (N <= 3, the values of the reference's callers) -- the formulation csrc/meshenv_samples.h uses.
+
+    The reference keeps ONE shared list: a node is appended while the list is shorter than N and written at its depth's
+    position afterwards.  With N = 3 that matters exactly once: when the first second-level node a0 has no admissible
+    child, the list is still [root, a0] when the next node a1 arrives, so a1 lands BEHIND a0 -- its children are filtered
+    against [root, a0] (not a1) and come out as [root, a0, child].  From then on the list is full and positions are right."""
+    assert 1 <= N <= 3
+    if N == 1:
+        return [[root]]
+    level1 = [a for a in adj[root] if a not in excluded and a != root]
+    if N == 2:
+        return [[root, a] for a in level1]
+    out: List[List[int]] = []
+    first_dead = False
+    for k, a in enumerate(level1):
+        behind = k == 1 and first_dead
+        shown, skip = (level1[0], level1[0]) if behind else (a, a)
+        kids = [b for b in adj[a] if b not in excluded and b != root and b != skip]
+        if k == 0:
+            first_dead = not kids
+        out.extend([root, shown, b] for b in kids)
+    return out
 
 
 def _radius_neighbors(xy, base: int, start: int, end: int, exclusion: Sequence[int], radius: float, N: int):
@@ -141,10 +155,8 @@ def extract_samples_2(quads, vertex_xy, n0: int, n_neighbor: int, n_radius: int,
             continue
         for i in range(4):
             rp, l_p, r_p, target = ev[i], ev[(i + 1) % 4], ev[i - 1], ev[i - 2]
-            l_paths: List[List[int]] = []
-            _get_nodes(adj, l_p, [rp, r_p], n_neighbor - 1, [], l_paths, n_neighbor)
-            r_paths: List[List[int]] = []
-            _get_nodes(adj, r_p, [rp, l_p], n_neighbor - 1, [], r_paths, n_neighbor)
+            l_paths = neighbour_paths(adj, l_p, [rp, r_p], n_neighbor)
+            r_paths = neighbour_paths(adj, r_p, [rp, l_p], n_neighbor)
             fans = _radius_neighbors(xy, rp, l_p, r_p, [rp, l_p, r_p, target], radius, n_radius)
             for rr, mm, ll in itertools.product([p for p in r_paths if len(p) == n_neighbor], fans,
                                                 [p for p in l_paths if len(p) == n_neighbor]):

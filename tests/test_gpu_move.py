@@ -183,9 +183,12 @@ def test_single_env_move_and_static_reset_follow_the_reference_surface():
 
 
 def test_extract_samples_2_from_the_device_mesh_equals_the_reference():
-    """general/mesh.py:1438-1489 on the mesh the DEVICE generated from the recorded actions: the reference's own
-    (all_samples, types, outputs), value for value -- element log, vertex table and neighbour order all line up."""
+    """general/mesh.py:1438-1489 through the drop-in class (device kernel, meshenv_extract_samples) on the mesh the DEVICE
+    generated from the recorded actions: the reference's own (all_samples, types, outputs) -- element log, vertex table and
+    neighbour order all line up; values identical except the last bits of the synthetic sector points' distances
+    (tests/test_gpu_samples.py states the bar)."""
     from reinforcementlearning4meshgeneration_amd import BoudaryEnv
+    from test_gpu_samples import _compare
     for name in ("samples_boundary0_post", "samples_star_ebrd"):
         tr = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
         env = BoudaryEnv([tuple(p) for p in tr["vertex_xy"][:int(tr["n0"])]])
@@ -194,7 +197,7 @@ def test_extract_samples_2_from_the_device_mesh_equals_the_reference():
             env.step(a)
         nn, nr, rad, idx, thr = tr["params"]
         samples, types, outputs = env.extract_samples_2(None, int(nn), int(nr), rad, index=int(idx), quality_threshold=float(thr))
-        assert np.array_equal(np.array(samples, np.float64), tr["samples"])
-        assert np.array_equal(np.array(types, np.float64).reshape(-1), tr["types"])
-        assert np.array_equal(np.array(outputs, np.float64), tr["outputs"])
+        assert isinstance(samples, list) and isinstance(types[0], list) and len(types[0]) == 1
+        _compare(np.array(samples, np.float64), np.array(types, np.float64).reshape(-1), np.array(outputs, np.float64),
+                 tr["samples"], tr["types"], tr["outputs"], int(nn), int(nr))
         env.close()

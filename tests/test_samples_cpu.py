@@ -1,4 +1,4 @@
-"""CPU: samples.extract_samples_2 against the reference's MeshGeneration.extract_samples_2 (general/mesh.py:1438-1489)
+"""CPU: tests/samples_host.extract_samples_2 (the host restatement the GPU tests compare the device kernel with) against the reference's MeshGeneration.extract_samples_2 (general/mesh.py:1438-1489)
 on meshes the reference generated (tests/golden/samples_*.npz, oracle/gen_samples_golden.py): same samples in the same
 order, value for value (pure Python float arithmetic on both sides)."""
 import glob
@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN_DIR
-from reinforcementlearning4meshgeneration_amd.samples import extract_samples_2, segment_lists
+from samples_host import extract_samples_2, segment_lists
 
 NAMES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, "samples_*.npz")))
 
