@@ -130,7 +130,7 @@ struct ActorHead {
 // standalone kernel one layer ahead is faster: 8.11 against 8.27 us)
 __device__ __forceinline__ void actor_request_weights(ActorHead &hd, const ActorWeights &W, int t, const bool all3 = false)
 {
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar also when t is an opaque value
     hd.have_r3 = all3;
     if (wave < kActWaves) {
         load_layer<2>(hd.r1, W.w1p, wave, lane);
@@ -149,7 +149,7 @@ __device__ __forceinline__ void actor_forward_tile(const ActorWeights &W, ActorH
                                                    float *__restrict__ eps_out, float *lds, int t, int n_threads)
 {
     float *bufA = lds, *bufB = lds + kActEnvs * kActStride, *eps_lds = lds + 2 * kActEnvs * kActStride;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // (k_step_group_actor_T passes an opaque thread id)
     const bool worker = wave < kActWaves;
     LayerRegs<2> &r1 = hd.r1;
     LayerRegs<8> &r2 = hd.r2;
