@@ -125,16 +125,22 @@ def cpu_baseline(n_envs, seed, doms, env_domain, wl, budget_s=12.0):
     n_atan2, n_sin, n_cos = math_calls(reset=True)
     one = n_envs * T1 / dt1
     affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # 16 = the CPU share of a one-GPU box of the pool (more threads than that are not this job's cores)
-    cores = max(1, min(affinity, int(os.environ.get("MESHENV_CPU_THREADS", "16"))))
-    dtc = run(2, cores)
-    Tn = max(8, min(4000, int(0.5 * budget_s / (dtc / 2))))
-    dtn = run(Tn, cores)
-    allc = n_envs * Tn / dtn
+    # "all cores": 16 threads = the CPU share of a one-GPU box of the pool, and -- where the affinity mask allows more -- up
+    # to 64 as well (a cgroup quota of 16 cores makes that run no faster: both are measured, the better one is reported)
+    want = int(os.environ.get("MESHENV_CPU_THREADS", "0"))
+    tries = [want] if want > 0 else sorted({max(1, min(affinity, 16)), max(1, min(affinity, 64))})
+    runs = []
+    for cores in tries:
+        dtc = run(2, cores)
+        Tn = max(8, min(4000, int(0.5 * budget_s / len(tries) / (dtc / 2))))
+        dtn = run(Tn, cores)
+        runs.append(dict(value=n_envs * Tn / dtn, cores=cores, steps=Tn))
+    best = max(runs, key=lambda r: r["value"])
+    allc, cores, Tn = best["value"], best["cores"], best["steps"]
     per = float(n_envs * T1)
     return dict(value=one, unit="env-steps/s", cores=1, kind="port", cpu_model=cpu_model(),
                 sample=f"{n_envs} envs on {wl} x {T1} uniform-random vector steps, oracle/meshenv_ref.c, 1 thread",
-                all_cores=dict(value=allc, cores=cores, sched_getaffinity=affinity, cpu_count=os.cpu_count(),
+                all_cores=dict(value=allc, cores=cores, sched_getaffinity=affinity, cpu_count=os.cpu_count(), thread_counts_tried=runs,
                                sample=f"{n_envs} envs x {Tn} steps, OpenMP over envs, {cores} threads "
                                       f"(sched_getaffinity allows {affinity}, the machine has {os.cpu_count()})"),
                 fp64_transcendentals_per_env_step=dict(
