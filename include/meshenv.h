@@ -179,6 +179,15 @@ int meshenv_step_kernel(const MeshEnv *h);
  * MESHENV_LIBM_EXACT=0 is set), the smoothers use x * x and agree with the reference to one ulp per squaring instead of
  * bit for bit; -1: not checked yet (no smoothing call so far).  The reference has no counterpart: it IS that libm. */
 int meshenv_libm_exact(const MeshEnv *h);
+/* Every clockwise angle (Vertex.to_find_clockwise_angle, general/components.py:99-108) is -atan2(cross, dot) rounded to
+ * 1e-4 rad.  The kernels take ocml's atan2, which is within an ulp of the libm the reference calls, and re-evaluate the
+ * few angles that sit on a rounding boundary (k + 0.5) e-4 -- the front smoother constructs such angles -- with a
+ * restatement of glibc's atan2 (csrc/meshenv_libm.h) whose table is read from the libm image of the running process and
+ * which is validated against that libm's atan2 when the first handle is created.  Returns 1: validated, the quantised
+ * angles are the reference's in every case; 0: table not found / another algorithm (the boundary cases then take a
+ * correctly rounded atan2, which agrees with glibc's in 99.93 % of them), or MESHENV_LIBM_EXACT=0 (ocml only).
+ * Host-only: needs no GPU. */
+int meshenv_atan2_exact(void);
 
 /*
  * reset(): rl/boundary_env.py:67-84 for every env whose mask byte is non-zero (all envs when

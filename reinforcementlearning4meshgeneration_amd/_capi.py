@@ -45,7 +45,7 @@ EXPORTS = [
     "meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid", "meshenv_step_kernel",
     "meshenv_create_random", "meshenv_get_domain", "meshenv_smooth", "meshenv_smooth_final", "meshenv_get_not_valid_ids", "meshenv_step_actor",
     "meshenv_libm_exact", "meshenv_create_random_density", "meshenv_density_rings",
-    "meshenv_step_actor_multi", "meshenv_extract_samples",
+    "meshenv_step_actor_multi", "meshenv_extract_samples", "meshenv_atan2_exact",
 ]
 
 
@@ -104,6 +104,8 @@ def load():
     L.meshenv_step_kernel.restype = C.c_int
     L.meshenv_libm_exact.argtypes = [vp]
     L.meshenv_libm_exact.restype = C.c_int
+    L.meshenv_atan2_exact.argtypes = []
+    L.meshenv_atan2_exact.restype = C.c_int
     L.meshenv_reset.argtypes = [vp, u8p, f32p]
     L.meshenv_reset_static.argtypes = [vp, u8p, f32p, C.c_int]
     L.meshenv_move.argtypes = [vp, vp, vp, vp, vp, vp, vp]

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "meshenv_libm.h"
+
 #ifndef MESHENV_NOINLINE
 #define MESHENV_NOINLINE __noinline__
 #endif
@@ -92,7 +94,30 @@ __device__ __forceinline__ float round4_npf(float x) { return rintf(x * 1e4f) / 
 // ---------------------------------------------------------------------------------- transcendentals
 // One out-of-line copy of each libm-style routine: the kernels evaluate them for a handful of lanes per
 // call site ("job lanes"), so sharing the body keeps the kernel inside the instruction cache.
-__device__ MESHENV_NOINLINE double atan2_nc(double y, double x) { return atan2(y, x); }
+// atan2: ocml's, which is within an ulp of the reference's libm and therefore gives the same 1e-4 quantum of the clockwise
+// angle (every use but two feeds cw_finish) -- except when the angle sits within ~1e-15 of a rounding boundary
+// (k + 0.5) e-4, where the last bit decides.  Those (2e-7 of random angles with the band below; every half-quantum angle
+// the front smoother constructs) are re-evaluated the way glibc does, bit for bit (csrc/meshenv_libm.h, atan2_tie).
+// The band is 1e-7 quanta = 1e-11 rad on either side, four orders of magnitude above ocml's error.
+// Three pieces so that the common path stays a LEAF call: with the tie-breaker inlined into the shared body its SGPR
+// pressure made the compiler park exec in a callee-saved VGPR, i.e. a scratch store + load per call (+0.5 us per step);
+// the band test is inlined at the call sites (its multiply / floor are the ones cw_finish needs anyway) and the
+// tie-breaker is its own out-of-line function that only the kernels -- non-leaf already -- call.
+__device__ MESHENV_NOINLINE double atan2_ocml_nc(double y, double x) { return atan2(y, x); }
+__device__ MESHENV_NOINLINE double atan2_tie_nc(double y, double x, double t) { return atan2_tie(y, x, t); }
+__device__ __forceinline__ double atan2_nc(double y, double x)
+{
+    double t = atan2_ocml_nc(y, x);
+#ifdef MESHENV_NO_ATAN_TIE
+    return t;
+#endif
+    const double theta = -t;
+    const double ang = signbit(theta) ? 2 * 3.141592653589793 + theta : theta;
+    const double yq = ang * 1e4;
+    const double fr = yq - floor(yq);
+    if (__builtin_expect(fabs(fr - 0.5) < 1e-7, 0)) t = atan2_tie_nc(y, x, t);
+    return t;
+}
 struct SinCos {
     double s, c;
 };
@@ -216,7 +241,7 @@ __device__ __forceinline__ double cw(P2 s, P2 p1, P2 p2)
 // a full memory round trip per call)
 __device__ MESHENV_NOINLINE bool sin_rounds_to_zero_exact(double c, double d)
 {
-    return round4_py(sin(cw_finish(atan2(c, d)))) == 0.0;
+    return round4_py(sin(cw_finish(atan2_nc(c, d)))) == 0.0;
 }
 
 __device__ __forceinline__ bool sin_rounds_to_zero(double c, double d)

@@ -6,11 +6,13 @@
 #include "../../include/meshenv.h"
 
 #include <hip/hip_runtime.h>
+#include <link.h>
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -26,6 +28,94 @@ using namespace meshenv;
 
 namespace {
 thread_local std::string g_create_error;
+
+// ---- glibc's atan2, restated (csrc/meshenv_libm.h): the 241 x 7 table comes out of the libm image of this process.
+// A record is {x_i, atan(x_i), 1 / (1 + x_i^2), ...} with x_i within 1/256 of (i + 16) / 256; the scan accepts the first
+// 8-byte-aligned run of 241 such records in a readable segment of libm.so.
+struct AtanHost {
+    std::vector<double> cij;   // empty: not found
+    int mode = 0;              // 2 restated glibc validated against this libm, 1 correctly rounded (atan2_cr), 0 ocml only
+};
+
+static bool atan_row_ok(const double *r, int i)
+{
+    const double x = r[0];
+    if (!(std::fabs(x - (i + 16) / 256.0) < 1.0 / 256.0)) return false;
+    return std::fabs(r[1] - std::atan(x)) < 1e-15 && std::fabs(r[2] * (1.0 + x * x) - 1.0) < 1e-12;
+}
+
+static int atan_scan_cb(struct dl_phdr_info *info, size_t, void *data)
+{
+    AtanHost *st = (AtanHost *)data;
+    if (!st->cij.empty() || !info->dlpi_name || !std::strstr(info->dlpi_name, "libm.so")) return 0;
+    const size_t bytes = sizeof(double) * kAtanRows * kAtanCols;
+    for (int k = 0; k < info->dlpi_phnum; k++) {
+        const ElfW(Phdr) *ph = &info->dlpi_phdr[k];
+        if (ph->p_type != PT_LOAD || !(ph->p_flags & PF_R) || ph->p_memsz < bytes) continue;
+        const unsigned char *base = (const unsigned char *)(info->dlpi_addr + ph->p_vaddr);
+        size_t o = (8 - ((uintptr_t)base & 7)) & 7;
+        for (; o + bytes <= ph->p_memsz; o += 8) {
+            double r[3];
+            std::memcpy(r, base + o, sizeof r);
+            if (!(r[0] > 0.06 && r[0] < 0.07) || !atan_row_ok(r, 0)) continue;
+            std::vector<double> t((size_t)kAtanRows * kAtanCols);
+            std::memcpy(t.data(), base + o, bytes);
+            bool all = true;
+            for (int i = 0; i < kAtanRows && all; i++) all = atan_row_ok(t.data() + (size_t)kAtanCols * i, i);
+            if (all) { st->cij.swap(t); return 1; }
+        }
+    }
+    return 0;
+}
+
+// atan2_glibc against the atan2 of this process on 2^18 arguments: all four octants, both the polynomial (u < 1/16) and
+// the table branch, lattice (4-decimal) and unrestricted coordinates, and the half-quantum angles the front smoother builds.
+static bool atan_validate(const std::vector<double> &cij)
+{
+    unsigned long long s = 0x9E3779B97F4A7C15ULL;
+    auto next = [&s]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    auto unit = [&next]() { return (double)(next() >> 11) / 9007199254740992.0; };
+    for (int n = 0; n < (1 << 18); n++) {
+        double y = 6.0 * unit() - 3.0, x = 6.0 * unit() - 3.0;
+        const int kind = n & 3;
+        if (kind == 1) { y = std::round(y * 1e4) / 1e4; x = std::round(x * 1e4) / 1e4; }
+        else if (kind == 2) y = std::ldexp(y, (int)(next() % 60) - 30);
+        else if (kind == 3) {
+            const double h = ((double)(next() % 62832) + 0.5) * 1e-4, sc = 0.01 + 3.0 * unit();
+            y = -std::sin(h) * sc; x = std::cos(h) * sc;
+        }
+        bool ok = false;
+        const double mine = atan2_glibc(y, x, cij.data(), ok);
+        if (ok && f64_bits(mine) != f64_bits(std::atan2(y, x))) return false;
+    }
+    return true;
+}
+
+static const AtanHost &atan_host()
+{
+    static AtanHost st;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *off = std::getenv("MESHENV_LIBM_EXACT");   // "0": ocml's atan2 everywhere (as before round 3)
+        if (off && off[0] == '0') { st.mode = 0; return; }
+        volatile double one = 1.0;
+        (void)std::atan2(one, one);   // keeps libm's atan2 linked and resolved
+        dl_iterate_phdr(atan_scan_cb, &st);
+        st.mode = (!st.cij.empty() && atan_validate(st.cij)) ? 2 : 1;
+    });
+    return st;
+}
+
+// table + mode into the current device's copy of the module globals (13.5 KB; every handle creation and selftest does it)
+static hipError_t upload_atan_state()
+{
+    const AtanHost &st = atan_host();
+    hipError_t e = hipSuccess;
+    if (st.mode == 2) e = hipMemcpyToSymbol(HIP_SYMBOL(g_atan_cij), st.cij.data(), sizeof(double) * st.cij.size());
+    const int mode = st.mode;
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_atan_mode), &mode, sizeof mode);
+    return e;
+}
 }
 
 struct MeshEnv {
@@ -250,6 +340,7 @@ static int create_impl(int device, int n_domains, const int32_t *dom_offsets_hos
         CREATE_HIP(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_init_domains, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
     }
+    CREATE_HIP(upload_atan_state());   // the tie-breaker of every quantised angle (csrc/meshenv_geom.h, atan2_nc)
 
     // Single-step kernel variant.  The CU-group kernel (G envs per workgroup, SIMD-balanced updates) pays off in the
     // latency-bound regime only: one workgroup per CU (n_envs <= 256 * G) with G >= 8; measured on MI355X,
@@ -690,6 +781,7 @@ int meshenv_max_ring(const MeshEnv *h) { return h ? h->max_ring : MESHENV_E_ARG;
 int meshenv_group_size(const MeshEnv *h) { return h ? h->group : MESHENV_E_ARG; }
 int meshenv_step_kernel(const MeshEnv *h) { return h ? (h->group > 1 ? (h->spec ? 2 : 1) : 0) : MESHENV_E_ARG; }
 int meshenv_libm_exact(const MeshEnv *h) { return h ? h->libm_exact : MESHENV_E_ARG; }
+int meshenv_atan2_exact(void) { return atan_host().mode == 2 ? 1 : 0; }
 
 int meshenv_reset_static(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev, int is_static)
 {
@@ -1299,7 +1391,7 @@ __global__ void k_selftest(int what, int n, const double *in, double *out, int l
     else if (what == 8) {  // cw_fast against the exact form: 0 equal, 1 guard band raised (and equal after the fallback), 2 MISMATCH
         bool ne;
         const double f = cw_fast(in[2 * i], in[2 * i + 1], ne);
-        const double e = cw_finish(atan2(in[2 * i], in[2 * i + 1]));
+        const double e = cw_finish(atan2_nc(in[2 * i], in[2 * i + 1]));
         out[i] = ne ? 1.0 : ((f == e && signbit(f) == signbit(e)) ? 0.0 : 2.0);
     } else if (what == 9 || what == 10) {
         // the front smoother's vertex constructions (csrc/meshenv_smooth.h): 9 doubles = which (0 middle_vertex, 1 side_vertex,
@@ -1321,6 +1413,12 @@ __global__ void k_selftest(int what, int n, const double *in, double *out, int l
         }
         out[i] = f.raised ? __builtin_nan("") : (what == 9 ? r.x : r.y);
     } else if (what == 11) out[i] = pow2_glibc(in[i]);   // against the host libm's pow(x, 2.0)
+    else if (what == 12) out[i] = cw_finish(atan2_nc(in[2 * i], in[2 * i + 1]));   // the quantised angle of terms (c, d)
+    else if (what == 13) {   // the tie-breaker alone, against the host libm's atan2; NaN outside its domain
+        bool ok;
+        const double t = atan2_glibc(in[2 * i], in[2 * i + 1], g_atan_cij, ok);
+        out[i] = ok ? t : __builtin_nan("");
+    } else if (what == 14) out[i] = atan2_cr(in[2 * i], in[2 * i + 1]);
 }
 
 int meshenv_selftest(int device, int what, int n, int in_per_item, const double *in_host, double *out_host)
@@ -1346,6 +1444,7 @@ int meshenv_selftest(int device, int what, int n, int in_per_item, const double 
         in_host = staged.data();
     }
     if (hipMemcpy(din, in_host, sizeof(double) * (size_t)n * in_per_item, hipMemcpyHostToDevice) != hipSuccess) rc = MESHENV_E_HIP;
+    if (rc == MESHENV_OK && upload_atan_state() != hipSuccess) rc = MESHENV_E_HIP;
     if (rc == MESHENV_OK) {
         hipLaunchKernelGGL(k_selftest, dim3((n + 63) / 64), dim3(64), 0, nullptr, what, n, din, dout,
                            (what == 9 || what == 10) ? validate_pow2() : 0);

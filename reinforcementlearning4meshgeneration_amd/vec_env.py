@@ -351,6 +351,12 @@ class MeshVecEnv:
         x * x (another libm, or MESHENV_LIBM_EXACT=0), -1 = no smoothing call yet."""
         return int(self._L.meshenv_libm_exact(self._handle))
 
+    @property
+    def atan2_exact(self) -> int:
+        """meshenv_atan2_exact: 1 = angles on a 1e-4 rounding boundary are decided by a validated restatement of the running
+        libm's atan2 (so every quantised angle is the reference's), 0 = by a correctly rounded atan2 or ocml's."""
+        return int(self._L.meshenv_atan2_exact())
+
     def smooth_pave(self, mask=None, iteration: int = 400, interior: bool = True, static: bool = False,
                     which: str = "current"):
         """MeshGeneration.smooth_pave(boundary.vertices, updated_boundary.vertices, iteration=iteration, interior=interior)

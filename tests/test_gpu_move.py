@@ -156,6 +156,55 @@ def test_self_touching_front_moves_in_lockstep_with_the_oracle():
     env.close()
 
 
+def test_half_quantum_angle_after_a_front_smoothing_rounds_like_the_reference():
+    """The second move campaign (profiles/r03_move_campaign_seed1105.log, before the fix: 16 observation entries in 8 moves,
+    all one state of env 483 on boundary(2)) replayed for that domain's 64 envs: the front smoother had put a vertex at
+    (4, 1 / tan(0.76305)), the angle measured back from it is 0.76304999999999992 -- 8e-17 below the rounding boundary -- and
+    ocml's atan2 returned the double above it.  With the boundary cases decided by glibc's own algorithm
+    (csrc/meshenv_libm.h, atan2_glibc) every entry is the oracle's, this state's 0.7630 included."""
+    import torch
+    from oracle.ref_lib import RefEnv
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv
+    from reinforcementlearning4meshgeneration_amd.domains import boundary, random_domain
+
+    def golden_domain(name):
+        return [tuple(p) for p in np.load(os.path.join(GOLDEN_DIR, name + ".npz"))["domain_xy"]]
+
+    doms = [boundary(0), boundary(-1), boundary(1), boundary(2)] + \
+           [golden_domain(x) for x in ("boundary16_biased_s2", "random1_1_biased_s1", "star_biased_s6")] + \
+           [random_domain(7000 + k) for k in range(25)]
+    n, T = 2048, 430
+    env_domain = (np.arange(n) % len(doms)).astype(np.int32)
+    env = MeshVecEnv(doms, env_domain=env_domain, auto_reset=False, log_capacity=512)
+    assert env.atan2_exact == 1
+    sel = [int(k) for k in np.flatnonzero(env_domain == 3)]
+    refs = {k: RefEnv.from_points(doms[3], cap_new=512) for k in sel}
+    env.reset(static=True)
+    for r in refs.values():
+        r.reset(static=True)
+    rng = np.random.default_rng(1105)
+    seen_state = differing = compared = 0
+    for t in range(T):
+        pts = np.stack([rng.uniform(0.05, 0.45, n), rng.uniform(0.2, 1.5, n)], axis=1)
+        typ = rng.uniform(0, 1, n)
+        o, d, c, code = [x.cpu().numpy() for x in env.move(torch.from_numpy(pts), torch.from_numpy(typ))]
+        mask = ((d != 0) | (code >= 2)).astype(np.uint8)
+        for k in sel:
+            o_r, d_r, c_r, code_r = refs[k].move(pts[k], typ[k])
+            assert code[k] == code_r and (code_r == 2 or (bool(d[k]) == d_r and bool(c[k]) == c_r)), (t, k)
+            if code_r == 0:
+                compared += 1
+                differing += int((o[k] != o_r).sum())
+                seen_state += int(k == 483 and o_r[3] == np.float32(0.763) and o_r[5] == np.float32(0.763))
+            if d_r or code_r >= 2:
+                refs[k].reset(static=True)
+        if mask.any():
+            env.reset(mask=torch.from_numpy(mask), static=True)
+    print("half-quantum state: observations compared", compared, "entries differing", differing, "times the state was observed", seen_state)
+    assert seen_state >= 5 and differing == 0
+    env.close()
+
+
 def test_single_env_move_and_static_reset_follow_the_reference_surface():
     from reinforcementlearning4meshgeneration_amd import BoudaryEnv
     tr = dict(np.load(os.path.join(GOLDEN_DIR, "move_hexagon_s3.npz")))

@@ -182,3 +182,51 @@ def test_device_pow2_is_the_host_libms_pow():
     assert np.array_equal(got.view(np.int64), want.view(np.int64))
     differs = int((want != x * x).sum())
     assert differs > 1000          # the sample does contain the arguments the restatement exists for
+
+
+def test_angles_on_a_quantisation_boundary_are_decided_like_the_host_libm():
+    """Vertex.to_find_clockwise_angle rounds -atan2(cross, dot) to 1e-4 rad (general/components.py:99-108).  The front
+    smoother constructs vertices at tan(q e-4 / 2) of a quantised angle, so the next observation measures a half-quantum
+    angle back and the LAST BIT of atan2 picks the quantum (profiles/r03_move_campaign_seed1105.log: one such state, ocml
+    0.7631 against the reference's 0.7630).  atan2_nc re-evaluates those angles with glibc's algorithm restated
+    (csrc/meshenv_libm.h, table read from the running libm): (a) that restatement is the host's math.atan2 bit for bit on
+    2.5e6 arguments; (b) the quantised angle equals the reference expression on 5e5 half-quantum constructions, the
+    campaign's own state included; (c) a correctly rounded atan2 would not do -- glibc's is not (0.07 % of arguments)."""
+    import math
+    from reinforcementlearning4meshgeneration_amd import _capi
+    assert _capi.load().meshenv_atan2_exact() == 1
+    rng = np.random.default_rng(21)
+    n = 1_000_000
+    gen = rng.uniform(-3, 3, (n, 2))
+    lat = np.round(rng.uniform(-3, 3, (n, 2)), 4)
+    lat = lat[(lat != 0).all(axis=1)]
+    k = rng.integers(1, 62832, 500_000)
+    h = (k + 0.5) * 1e-4
+    sc = 10.0 ** rng.uniform(-3, 3, len(k))
+    half = np.stack([-np.sin(h) * sc, np.cos(h) * sc], axis=1)
+    # the construction itself: ref above a horizontal front at height 1 / tan(h), neighbours below it and to the left
+    hq = h[h < 1.5]
+    yv = 1.0 / np.tan(hq)
+    built = np.stack([-yv, yv * yv], axis=1)             # cross, dot of (0, -y) and (-1, -y)
+    seen = np.array([[-1.0457258277606645, 1.0457258277606645 ** 2]])
+    items = np.concatenate([gen, lat, half, built, seen])
+    got = _run(13, items)
+    ok = ~np.isnan(got)
+    want = np.array([math.atan2(float(a), float(b)) for a, b in items])
+    assert ok.mean() > 0.999 and ok[len(gen) + len(lat):].all()
+    assert np.array_equal(got[ok].view(np.int64), want[ok].view(np.int64))
+    # (b) the quantised angle
+    q = np.concatenate([half, built, seen])
+    ang = _run(12, q)
+    ref = np.empty(len(q))
+    for i, (c, d) in enumerate(q):
+        theta = -math.atan2(float(c), float(d))
+        ref[i] = round(theta, 4) if math.copysign(1.0, theta) >= 0 else round(2 * math.pi + theta, 4)
+    assert np.array_equal(ang, ref)
+    assert ang[-1] == 0.763
+    # (c) correctly rounded is not the libm's
+    cr = _run(14, items[:len(gen)])
+    frac = float((cr != want[:len(gen)]).mean())
+    print(f"correctly rounded atan2 differs from the host libm's in {frac:.2e} of random arguments")
+    assert 1e-4 < frac < 3e-3
+    assert (np.abs(cr - want[:len(gen)]) <= np.spacing(np.abs(want[:len(gen)]))).all()

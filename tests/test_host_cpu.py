@@ -26,6 +26,15 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert p.radius == 4 and abs(p.max_ref_angle - 0.972 * np.pi) < 1e-15 and p.key_lambda == 0.618
 
 
+def test_the_host_finds_and_validates_the_libms_atan2():
+    """meshenv_atan2_exact (host-only, no GPU): the library locates glibc's 241 x 7 atan table in the libm image of this
+    process and its restatement of __ieee754_atan2 (csrc/meshenv_libm.h) agrees with math.atan2's libm on the 2^18
+    validation arguments -- on this image's glibc 2.35 it must, or the device's tie-breaker for quantised angles is the
+    weaker correctly-rounded stand-in."""
+    from reinforcementlearning4meshgeneration_amd import _capi
+    assert _capi.load().meshenv_atan2_exact() == 1
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a GPU the product path must fail loudly, never compute on the host."""
     import torch
