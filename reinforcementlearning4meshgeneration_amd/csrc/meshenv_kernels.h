@@ -1202,19 +1202,44 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
             // the new-vertex quad survived the corner test: hand it out before the point-in-polygon pass
             if (hook && have_pre) spec_post(hook, c, true, 0, index, new_point);
         }
-        const bool inside = point_inside(c, prm, new_point);
-        MESHENV_STAMP(c, 2);
-        if (!inside) {
-            d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;
-            return d;
-        }
-        // second ring pass: find_same_point + the distance filter of the quad [new, i-1, i, i+1]
         NearFilter f;
         f.ref = p0;
         f.mp0 = -1; f.mp1 = wrapi(index - 1, n); f.mp2 = index; f.mp3 = wrapi(index + 1, n);
-        f.max_dist = quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3));
         bool same;
-        near_count = near_filter_pass(c, f, new_point, is_move ? 0.0 : prm.same_eps, same);
+#ifndef MESHENV_NO_FUSED_PIP
+        if (n <= 64) {
+            // One ring pass for the three per-vertex tests of a rule-0 point -- crossing parity (M:539-546), find_same_point
+            // and the distance filter of the quad [new, i-1, i, i+1]: their dependency chains are independent, so the
+            // slowest check of the workgroup (a valid rule-0 action, which pays for all three) overlaps them instead of
+            // running two passes back to back.  A point outside the ring pays ~55 instructions it used not to.
+            f.max_dist = quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3));
+            const bool in = lane < n;
+            const int ic = in ? lane : 0;
+            const P2 v = ldp(c, ic);
+            const bool counted = edge_counted(c, new_point, mkp(prm.ray_length, new_point.y), ic, in);
+            const bool sm = !is_move && in && dist(v, new_point) < prm.same_eps;
+            const bool near = in && nf_near(f, lane, v);
+            const bool inside = (__popcll(__ballot(counted)) & 1) != 0;
+            same = __ballot(sm) != 0ULL;
+            near_count = nf_compact(c, near, lane, 0);
+            MESHENV_STAMP(c, 2);
+            if (!inside) {
+                d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;
+                return d;
+            }
+        } else
+#endif
+        {
+            const bool inside = point_inside(c, prm, new_point);
+            MESHENV_STAMP(c, 2);
+            if (!inside) {
+                d.reward += c.n_elem ? -1.0 / c.n_elem : -1.0;
+                return d;
+            }
+            // second ring pass: find_same_point + the distance filter of the quad [new, i-1, i, i+1]
+            f.max_dist = quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3));
+            near_count = near_filter_pass(c, f, new_point, is_move ? 0.0 : prm.same_eps, same);
+        }
         if (same) {  // existing point: the rule -1 quad, B:168-175 (its own filter pass follows)
             rule = -1;
             if (hook) hook->stale = hook->posted;
