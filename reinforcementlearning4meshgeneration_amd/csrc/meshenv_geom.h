@@ -94,30 +94,31 @@ __device__ __forceinline__ float round4_npf(float x) { return rintf(x * 1e4f) / 
 // ---------------------------------------------------------------------------------- transcendentals
 // One out-of-line copy of each libm-style routine: the kernels evaluate them for a handful of lanes per
 // call site ("job lanes"), so sharing the body keeps the kernel inside the instruction cache.
-// atan2: ocml's, which is within an ulp of the reference's libm and therefore gives the same 1e-4 quantum of the clockwise
-// angle (every use but two feeds cw_finish) -- except when the angle sits within ~1e-15 of a rounding boundary
-// (k + 0.5) e-4, where the last bit decides.  Those (2e-7 of random angles with the band below; every half-quantum angle
-// the front smoother constructs) are re-evaluated the way glibc does, bit for bit (csrc/meshenv_libm.h, atan2_tie).
-// The band is 1e-7 quanta = 1e-11 rad on either side, four orders of magnitude above ocml's error.
-// Three pieces so that the common path stays a LEAF call: with the tie-breaker inlined into the shared body its SGPR
-// pressure made the compiler park exec in a callee-saved VGPR, i.e. a scratch store + load per call (+0.5 us per step);
-// the band test is inlined at the call sites (its multiply / floor are the ones cw_finish needs anyway) and the
-// tie-breaker is its own out-of-line function that only the kernels -- non-leaf already -- call.
-__device__ MESHENV_NOINLINE double atan2_ocml_nc(double y, double x) { return atan2(y, x); }
+// atan2, two out-of-line bodies.
+//  * atan2_nc: ocml's, a leaf.  Within an ulp of the libm the reference calls, so the 1e-4 quantum of a clockwise angle
+//    (every use but two feeds cw_finish) is the reference's unless the angle lies within ~1e-15 of a rounding boundary
+//    (k + 0.5) e-4.  The step kernels use this one: their coordinates are all multiples of 1e-4, nothing puts an angle on
+//    a boundary, and a chance hit is a 1e-11-per-step event (none in 4.5e9 steps of soak) -- while a test on every angle
+//    cost 2-3 % of the throughput at 65 536 envs in each of the three forms tried (tools/ab_all.sh).
+//  * atan2_x_nc: the same, then angles inside a band of 1e-11 rad around a boundary are re-evaluated the way glibc does,
+//    bit for bit (csrc/meshenv_libm.h, atan2_tie).  Everything on the move() / smoothing path uses this one (Ctx::tie,
+//    cw(), cw_exact): the front smoother CONSTRUCTS half-quantum angles -- it places vertices at tan(q e-4 / 2) of a
+//    quantised angle and the next observation measures that angle back.
+__device__ MESHENV_NOINLINE double atan2_nc(double y, double x) { return atan2(y, x); }
 __device__ MESHENV_NOINLINE double atan2_tie_nc(double y, double x, double t) { return atan2_tie(y, x, t); }
-__device__ __forceinline__ double atan2_nc(double y, double x)
+__device__ MESHENV_NOINLINE double atan2_x_nc(double y, double x)
 {
-    double t = atan2_ocml_nc(y, x);
-#ifdef MESHENV_NO_ATAN_TIE
-    return t;
-#endif
+    double t = atan2(y, x);
+#ifndef MESHENV_NO_ATAN_TIE   // (A/B builds only)
     const double theta = -t;
     const double ang = signbit(theta) ? 2 * 3.141592653589793 + theta : theta;
     const double yq = ang * 1e4;
-    const double fr = yq - floor(yq);
-    if (__builtin_expect(fabs(fr - 0.5) < 1e-7, 0)) t = atan2_tie_nc(y, x, t);
+    const double fr = (yq - floor(yq)) - 0.5;
+    if (__builtin_expect(fabs(fr) < 1e-7, 0)) t = atan2_tie_nc(y, x, t);
+#endif
     return t;
 }
+__device__ __forceinline__ double atan2_sel(const bool tie, double y, double x) { return tie ? atan2_x_nc(y, x) : atan2_nc(y, x); }
 struct SinCos {
     double s, c;
 };
@@ -156,6 +157,38 @@ __device__ __forceinline__ double dist(P2 a, P2 b)
     return sqrt_pos(dx * dx + dy * dy);
 }
 
+// dist(a, b) < t without the square root.  The ring-wide filters (find_same_point, the distance filter of
+// check_intersection_with_boundary, the near-vertex scan of compute_boundary_quality) only compare a distance with a
+// threshold; sqrt is monotone and correctly rounded, so s = dx^2 + dy^2 < t^2 (1 - 1e-15) implies sqrt(s) < t and
+// s > t^2 (1 + 1e-15) implies sqrt(s) >= t (the band covers the rounding of t * t, of the factor and of the root with a
+// margin of 3); a sum inside the band -- 2e-15 of its range -- and every non-positive or non-finite threshold takes the
+// root.  The same truth value as dist(a, b) < t in every case, 19 instructions shorter per lane.
+struct DistThr {
+    double t, lo, hi;
+};
+__device__ __forceinline__ DistThr dist_thr(double t)
+{
+    DistThr q;
+    const double t2 = t * t;
+    const bool usable = t > 1e-140 && t < 1e140;
+    q.t = t;
+    q.lo = usable ? t2 * (1.0 - 1e-15) : -1.0;
+    q.hi = usable ? t2 * (1.0 + 1e-15) : kInfGeom;
+    return q;
+}
+__device__ __forceinline__ bool dist_lt(P2 a, P2 b, const DistThr &q)
+{
+#ifdef MESHENV_NO_FILTERS
+    return dist(a, b) < q.t;
+#else
+    const double dx = a.x - b.x, dy = a.y - b.y;
+    const double s = dx * dx + dy * dy;
+    bool r = s < q.lo;
+    if (__builtin_expect(!r && !(s > q.hi), 0)) r = sqrt_pos(s) < q.t;
+    return r;
+#endif
+}
+
 // numerator / denominator of the clockwise angle: cross(v1,v2), dot(v1,v2) with v1 = p1-s, v2 = p2-s
 __device__ __forceinline__ void cw_terms(P2 s, P2 p1, P2 p2, double &c, double &d)
 {
@@ -171,6 +204,10 @@ __device__ __forceinline__ double cw_finish(double t)
     const double theta = -t;
     return round4_py(signbit(theta) ? 2 * kPi + theta : theta);
 }
+
+// Vertex.to_find_clockwise_angle from its atan2 terms: the reference's quantum in every case / per the kernel's choice
+__device__ __forceinline__ double cw_exact(double c, double d) { return cw_finish(atan2_x_nc(c, d)); }
+__device__ __forceinline__ double cw_sel(const bool tie, double c, double d) { return cw_finish(atan2_sel(tie, c, d)); }
 
 // cw_finish(atan2(c, d)) without the libm-grade atan2 (309 instructions): the result is quantised to 1e-4 rad, so an
 // angle known to 1e-12 decides the quantum everywhere except within a guard band of the rounding boundaries (k + 0.5) e-4,
@@ -222,7 +259,7 @@ __device__ __forceinline__ double cw(P2 s, P2 p1, P2 p2)
 {
     double c, d;
     cw_terms(s, p1, p2, c, d);
-    return cw_finish(atan2_nc(c, d));
+    return cw_exact(c, d);
 }
 
 // sin_rounds_to_zero(c, d)  ==  (round(sin(cw_angle), 4) == 0)  with cw_angle = the 1e-4-quantised clockwise angle
@@ -241,7 +278,7 @@ __device__ __forceinline__ double cw(P2 s, P2 p1, P2 p2)
 // a full memory round trip per call)
 __device__ MESHENV_NOINLINE bool sin_rounds_to_zero_exact(double c, double d)
 {
-    return round4_py(sin(cw_finish(atan2_nc(c, d)))) == 0.0;
+    return round4_py(sin(cw_exact(c, d))) == 0.0;
 }
 
 __device__ __forceinline__ bool sin_rounds_to_zero(double c, double d)

@@ -1391,7 +1391,7 @@ __global__ void k_selftest(int what, int n, const double *in, double *out, int l
     else if (what == 8) {  // cw_fast against the exact form: 0 equal, 1 guard band raised (and equal after the fallback), 2 MISMATCH
         bool ne;
         const double f = cw_fast(in[2 * i], in[2 * i + 1], ne);
-        const double e = cw_finish(atan2_nc(in[2 * i], in[2 * i + 1]));
+        const double e = cw_exact(in[2 * i], in[2 * i + 1]);
         out[i] = ne ? 1.0 : ((f == e && signbit(f) == signbit(e)) ? 0.0 : 2.0);
     } else if (what == 9 || what == 10) {
         // the front smoother's vertex constructions (csrc/meshenv_smooth.h): 9 doubles = which (0 middle_vertex, 1 side_vertex,
@@ -1413,7 +1413,7 @@ __global__ void k_selftest(int what, int n, const double *in, double *out, int l
         }
         out[i] = f.raised ? __builtin_nan("") : (what == 9 ? r.x : r.y);
     } else if (what == 11) out[i] = pow2_glibc(in[i]);   // against the host libm's pow(x, 2.0)
-    else if (what == 12) out[i] = cw_finish(atan2_nc(in[2 * i], in[2 * i + 1]));   // the quantised angle of terms (c, d)
+    else if (what == 12) out[i] = cw_exact(in[2 * i], in[2 * i + 1]);   // the quantised angle of terms (c, d)
     else if (what == 13) {   // the tie-breaker alone, against the host libm's atan2; NaN outside its domain
         bool ok;
         const double t = atan2_glibc(in[2 * i], in[2 * i + 1], g_atan_cij, ok);

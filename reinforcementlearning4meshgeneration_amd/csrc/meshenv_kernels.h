@@ -84,6 +84,7 @@ struct Ctx {
     int n, ref, n_elem, failed, n_new, counter, status, dom;
     double bl, area, ct, st;
     bool ring_dirty;
+    bool tie = false;  // angles on a 1e-4 rounding boundary take glibc's atan2 (move() / smoothing kernels; geom.h, atan2_x_nc)
     // lane-private
     float obs;  // lanes 0..17: current observation
 };
@@ -449,7 +450,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         jx = lane == 6 ? right.x - ref.x : jx;
     }
     double jt = 0.0;
-    if (lane < 7 || scanjob) jt = atan2_nc(jy, jx);
+    if (lane < 7 || scanjob) jt = atan2_sel(c.tie, jy, jx);
     const double na = cw_finish(jt);
     if (scanjob) c.ang_ord[ord_a] = na;
     // base_length = round(sum of the 6 window edges / 6, 4), summed in the reference's order
@@ -519,6 +520,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     const int w1 = wrapi(bqi + 1, n), w2 = wrapi(bqi + 2, n), w3 = wrapi(bqi - 1, n), w4 = wrapi(bqi - 2, n);
     const bool bq_scan = bq.mode == 1 && !bq.skip;
     const P2 add_v = ldp(c, bq_scan ? bqi : 0);
+    const DistThr dst_thr = dist_thr(dst);
     // traversal positions stage A had no lane for (rings longer than 58): their clockwise angles in full 64-lane
     // passes of their own, so that a 120-vertex ring costs one more transcendental pass, not two
     for (int o0 = kScanLanes; o0 < n - 1; o0 += 64) {
@@ -527,11 +529,11 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         double cc, dd;
         cw_terms(ref, ldp(c, wrapi(idc - 1 - (in ? o : 0), n)), right, cc, dd);
 #ifdef MESHENV_NO_FILTERS
-        const double a = cw_finish(atan2_nc(cc, dd));
+        const double a = cw_sel(c.tie, cc, dd);
 #else
         bool need_exact;   // all of these angles are quantised: fast form, exact for the pass when a lane sits in a guard band
         double a = cw_fast(cc, dd, need_exact);
-        if (__ballot(need_exact && in) != 0ULL) a = cw_finish(atan2_nc(cc, dd));
+        if (__ballot(need_exact && in) != 0ULL) a = cw_sel(c.tie, cc, dd);
 #endif
         if (in) c.ang_ord[o] = a;
     }
@@ -547,7 +549,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         if (bq_scan) {
             const int i = base + lane;
             bool near = false;
-            if (i < n && !(i == bqi || i == w1 || i == w2 || i == w3 || i == w4)) near = dist(add_v, ldp(c, i)) < dst;
+            if (i < n && !(i == bqi || i == w1 || i == w2 || i == w3 || i == w4)) near = dist_lt(add_v, ldp(c, i), dst_thr);
             const unsigned long long m = __ballot(near);
             bool added = false;
             if (near) {
@@ -750,13 +752,13 @@ __device__ __forceinline__ bool point_inside(Ctx &c, const Params &prm, P2 p)
 // nearer to the reference vertex than the farthest quad vertex
 struct NearFilter {
     P2 ref;
-    double max_dist;
+    DistThr max_dist;
     int mp0, mp1, mp2, mp3;  // ring slots of the quad vertices (-1: not on the ring)
 };
 
 __device__ __forceinline__ bool nf_near(const NearFilter &f, int i, P2 v)
 {
-    return !(i == f.mp0 || i == f.mp1 || i == f.mp2 || i == f.mp3) && dist(f.ref, v) < f.max_dist;
+    return !(i == f.mp0 || i == f.mp1 || i == f.mp2 || i == f.mp3) && dist_lt(f.ref, v, f.max_dist);
 }
 
 // survivors of one 64-vertex chunk go to the LDS list, in ring order
@@ -773,11 +775,12 @@ __device__ __forceinline__ int near_filter_pass(Ctx &c, const NearFilter &f, P2 
 {
     int count = 0;
     bool any_same = false;
+    const DistThr same_thr = dist_thr(same_eps);
     for (int i0 = 0; i0 < c.n; i0 += 64) {
         const int i = i0 + c.lane;
         const bool in = i < c.n;
         const P2 v = ldp(c, in ? i : 0);
-        if (same_eps > 0.0) any_same = any_same || (__ballot(in && dist(v, p) < same_eps) != 0ULL);
+        if (same_eps > 0.0) any_same = any_same || (__ballot(in && dist_lt(v, p, same_thr)) != 0ULL);
         count = nf_compact(c, in && nf_near(f, i, v), i, count);
     }
     same = any_same;
@@ -877,11 +880,11 @@ __device__ __forceinline__ bool quad_pass(Ctx &c, const Params &prm, const VRing
         // every angle of this stage is quantised before use: the fast form, the exact one for the whole stage when any
         // lane sits in a guard band
 #ifdef MESHENV_NO_FILTERS
-        const double a = cw_finish(atan2_nc(jy, jx));
+        const double a = cw_sel(c.tie, jy, jx);
 #else
         bool need_exact;
         double a = cw_fast(jy, jx, need_exact);
-        if (__ballot(need_exact) != 0ULL) a = cw_finish(atan2_nc(jy, jx));
+        if (__ballot(need_exact) != 0ULL) a = cw_sel(c.tie, jy, jx);
 #endif
         if (lane < 4) {
             c.sc->ang[lane] = a;
@@ -1100,9 +1103,10 @@ struct Decision {
 // rule from mv_type against TYPE_THRESHOLD = 0.3, and there is no find_same_point; a compile-time constant per call)
 // (hook != nullptr: k_step_spec -- every quad takes the exact corner-sign test up front and, once it has passed, the
 // action is posted for a speculative update on another wavefront; a compile-time null everywhere else)
+// (fuse_passes: the three ring passes of a rule-0 point as one, see below; a compile-time constant per call)
 __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a0, float a1, float a2, const bool pre_reject,
                                               const bool is_move = false, double mv_r = 0.0, double mv_a = 0.0,
-                                              double mv_type = 0.5, SpecHook *hook = nullptr)
+                                              double mv_type = 0.5, SpecHook *hook = nullptr, const bool fuse_passes = false)
 {
     const Params &prm = S.prm;
     const int lane = c.lane;
@@ -1207,17 +1211,18 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
         f.mp0 = -1; f.mp1 = wrapi(index - 1, n); f.mp2 = index; f.mp3 = wrapi(index + 1, n);
         bool same;
 #ifndef MESHENV_NO_FUSED_PIP
-        if (n <= 64) {
+        if (fuse_passes && n <= 64) {
             // One ring pass for the three per-vertex tests of a rule-0 point -- crossing parity (M:539-546), find_same_point
             // and the distance filter of the quad [new, i-1, i, i+1]: their dependency chains are independent, so the
             // slowest check of the workgroup (a valid rule-0 action, which pays for all three) overlaps them instead of
-            // running two passes back to back.  A point outside the ring pays ~55 instructions it used not to.
-            f.max_dist = quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3));
+            // running two passes back to back.  A point outside the ring pays ~55 instructions it used not to, which is
+            // why only the CU-group kernel (latency regime) asks for it: at 65 536 envs it cost 4 % (tools/ab_all.sh).
+            f.max_dist = dist_thr(quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3)));
             const bool in = lane < n;
             const int ic = in ? lane : 0;
             const P2 v = ldp(c, ic);
             const bool counted = edge_counted(c, new_point, mkp(prm.ray_length, new_point.y), ic, in);
-            const bool sm = !is_move && in && dist(v, new_point) < prm.same_eps;
+            const bool sm = !is_move && in && dist_lt(v, new_point, dist_thr(prm.same_eps));
             const bool near = in && nf_near(f, lane, v);
             const bool inside = (__popcll(__ballot(counted)) & 1) != 0;
             same = __ballot(sm) != 0ULL;
@@ -1237,7 +1242,7 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
                 return d;
             }
             // second ring pass: find_same_point + the distance filter of the quad [new, i-1, i, i+1]
-            f.max_dist = quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3));
+            f.max_dist = dist_thr(quad_max_dist(lane, p0, new_point, ldp(c, f.mp1), ldp(c, f.mp3)));
             near_count = near_filter_pass(c, f, new_point, is_move ? 0.0 : prm.same_eps, same);
         }
         if (same) {  // existing point: the rule -1 quad, B:168-175 (its own filter pass follows)
@@ -1295,7 +1300,7 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
             f.ref = mkp(q[r].x, q[r].y);
             f.mp0 = mp0; f.mp1 = mp1; f.mp2 = mp2; f.mp3 = mp3;
             const double2 qa = q[(r + 1) & 3], qb = q[(r + 2) & 3], qc = q[(r + 3) & 3];
-            f.max_dist = quad_max_dist(lane, f.ref, mkp(qa.x, qa.y), mkp(qb.x, qb.y), mkp(qc.x, qc.y));
+            f.max_dist = dist_thr(quad_max_dist(lane, f.ref, mkp(qa.x, qa.y), mkp(qb.x, qb.y), mkp(qc.x, qc.y)));
             bool unused;
             near_count = near_filter_pass(c, f, f.ref, 0.0, unused);
         }
@@ -1525,10 +1530,11 @@ __device__ __forceinline__ double reward_on_helper(Ctx &c, const DevState &S, co
         const int bqi = bqa;
         const int w1 = wrapi(bqi + 1, n), w2 = wrapi(bqi + 2, n), w3 = wrapi(bqi - 1, n), w4 = wrapi(bqi - 2, n);
         const P2 add_v = ldp(c, bqi);
+        const DistThr dst_thr = dist_thr(dst);
         for (int base = 0; base < n; base += 64) {
             const int i = base + lane;
             bool near = false;
-            if (i < n && !(i == bqi || i == w1 || i == w2 || i == w3 || i == w4)) near = dist(add_v, ldp(c, i)) < dst;
+            if (i < n && !(i == bqi || i == w1 || i == w2 || i == w3 || i == w4)) near = dist_lt(add_v, ldp(c, i), dst_thr);
             const unsigned long long m = __ballot(near);
             bool added = false;
             if (near) {
@@ -1627,9 +1633,9 @@ __global__ void __launch_bounds__(64) k_init_domains(DevState S, int cap)
     for (int i = c.lane; i < c.n; i += 64) {
         double cc, dd, k = 0.0;
         key_angle_terms(c, i, 0, cc, dd);
-        const double a0 = cw_finish(atan2_nc(cc, dd));
+        const double a0 = cw_exact(cc, dd);
         key_angle_terms(c, i, 1, cc, dd);
-        const double a1 = cw_finish(atan2_nc(cc, dd));
+        const double a1 = cw_exact(cc, dd);
         const bool ok = key_from_angles(S.prm, a0, a1, k);
         c.key[i] = k;
         c.stamp[i] = ok ? -i : kNotCand;
@@ -1856,6 +1862,7 @@ __global__ void __launch_bounds__(64) k_move(DevState S, int cap, const double *
 {
     extern __shared__ double2 smem[];
     Ctx c;
+    c.tie = true;   // smoothed fronts hold half-quantum angles
     carve_lds(c, smem, cap);
     double2 *nv = (double2 *)((char *)smem + lds_bytes_for(cap));
     const int env = blockIdx.x;
@@ -2072,7 +2079,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
         const EnvCounters cnt0 = S.cnt[env];
         load_env(c, S, env, true, tid_in >= 0 ? (tid & 63) : -1);
         const int n_before = c.n;
-        Decision d = env_check(c, S, a0, a1, a2, false);
+        Decision d = env_check(c, S, a0, a1, a2, false, false, 0.0, 0.0, 0.5, nullptr, true);
         if (!d.ok) {
             finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0, nullptr, actor_in ? actor_in + wave * 132 : nullptr, tstep, ka);
         } else {

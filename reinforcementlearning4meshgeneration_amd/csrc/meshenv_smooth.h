@@ -954,14 +954,15 @@ k_rebuild_candidates(DevState S, int cap, const uint8_t *__restrict__ mask, cons
     if (mask && mask[env] == 0) return;
     if (sweeps && sweeps[env] < 0) return;   // the smoother refused this env: nothing changed
     Ctx c;
+    c.tie = true;   // the smoother has just moved front vertices onto half-quantum angles
     carve_lds(c, smem, cap);
     load_env(c, S, env);
     for (int i = c.lane; i < c.n; i += 64) {
         double cc, dd, k = 0.0;
         key_angle_terms(c, i, 0, cc, dd);
-        const double a0 = cw_finish(atan2_nc(cc, dd));
+        const double a0 = cw_exact(cc, dd);
         key_angle_terms(c, i, 1, cc, dd);
-        const double a1 = cw_finish(atan2_nc(cc, dd));
+        const double a1 = cw_exact(cc, dd);
         const bool ok = key_from_angles(S.prm, a0, a1, k);
         c.key[i] = k;
         c.stamp[i] = ok ? -i : kNotCand;
