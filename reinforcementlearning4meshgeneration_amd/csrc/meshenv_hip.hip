@@ -145,6 +145,7 @@ struct MeshEnv {
     Reselect *pend = nullptr;          // [E] selection parked by the candidate rebuild (csrc/meshenv_smooth.h)
     float *pend_obs = nullptr;         // [E][18]
     bool reselect_pending = false;     // a rebuild ran since the last step kernel
+    bool front_moved = false;          // a front smoother ran since the last full reset: rings may hold off-lattice vertices
     bool smooth_final_ready = false;
     bool fused_ready = false;          // k_step_group_actor's LDS attribute set
     bool fused_T_ready = false;        // k_step_group_actor_T's
@@ -337,6 +338,10 @@ static int create_impl(int device, int n_domains, const int32_t *dom_offsets_hos
         CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_step<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_init_domains, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
     }
@@ -779,7 +784,7 @@ int meshenv_set_packed_output(MeshEnv *h, float *msg_dev)
 int meshenv_num_envs(const MeshEnv *h) { return h ? h->n_envs : MESHENV_E_ARG; }
 int meshenv_max_ring(const MeshEnv *h) { return h ? h->max_ring : MESHENV_E_ARG; }
 int meshenv_group_size(const MeshEnv *h) { return h ? h->group : MESHENV_E_ARG; }
-int meshenv_step_kernel(const MeshEnv *h) { return h ? (h->group > 1 ? (h->spec ? 2 : 1) : 0) : MESHENV_E_ARG; }
+int meshenv_step_kernel(const MeshEnv *h) { return h ? (h->group > 1 && !h->front_moved ? (h->spec ? 2 : 1) : 0) : MESHENV_E_ARG; }
 int meshenv_libm_exact(const MeshEnv *h) { return h ? h->libm_exact : MESHENV_E_ARG; }
 int meshenv_atan2_exact(void) { return atan_host().mode == 2 ? 1 : 0; }
 
@@ -790,6 +795,7 @@ int meshenv_reset_static(MeshEnv *h, const uint8_t *mask_dev, float *obs_dev, in
     hipLaunchKernelGGL(k_reset, dim3(h->n_envs), dim3(64), h->lds, h->stream, h->S, h->cap, mask_dev, obs_dev, 0,
                        (unsigned long long)h->steps_done, is_static ? 1 : 0, h->nv_count, h->nv_meta);
     HIP_TRY(h, hipGetLastError());
+    if (!mask_dev) h->front_moved = false;   // every ring is its domain's again: multiples of 1e-4 only
     return MESHENV_OK;
 }
 
@@ -904,6 +910,7 @@ static int launch_full_smoothing(MeshEnv *h, const uint8_t *mask_dev, int iterat
     MESHENV_ON_DEVICE(h);
     const int log_cap = h->S.prm.log_cap;
     const dim3 grid(h->n_envs), block(64);
+    h->front_moved = true;   // until the next full reset (launch_step)
     hipLaunchKernelGGL(k_smooth_front, grid, block, smooth_front_lds_bytes(h->cap, log_cap), h->stream, h->S, h->cap, mask_dev,
                        h->front_code, (const double *)h->front_tab, h->libm_exact, h->move_ready ? h->nv_xy : nullptr,
                        (const int32_t *)h->nv_count, (const int32_t *)h->nv_gid);
@@ -1111,7 +1118,10 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
     const size_t slot = (size_t)(h->ev_count % MESHENV_TIMING_POOL);
     const long long pos = h->timing > 0 ? (h->launch_count++ % (2LL * h->timing)) : -1;
     if (pos == 0) HIP_TRY(h, hipEventRecord(h->ev[2 * slot], h->stream));
-    if (n_steps == 1 && h->group > 1) {
+    // After a front smoothing (meshenv_smooth(interior = 0), or a meshenv_move that went through smooth_pave) a ring can hold
+    // vertices off the 1e-4 lattice, and with them clockwise angles that sit exactly on a rounding boundary: until every env
+    // has been reset, steps run the one-wave-per-env kernel in its tie-breaking instantiation (csrc/meshenv_geom.h).
+    if (n_steps == 1 && h->group > 1 && !h->front_moved) {
         const int G = h->group;
         const dim3 grid((h->n_envs + G - 1) / G), block(64 * G);
         GroupArgs A;
@@ -1130,8 +1140,16 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
     } else {
         const dim3 grid(h->n_envs), block(64);
 #define MESHENV_LAUNCH_STEP(MULTI, DEF)                                                                                      \
-    hipLaunchKernelGGL((k_step<MULTI, DEF>), grid, block, h->lds, h->stream, h->S, h->cap, n_steps, actions_dev, obs_dev,   \
-                       reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset, (unsigned long long)h->steps_done)
+    do {                                                                                                                     \
+        if (h->front_moved)                                                                                                  \
+            hipLaunchKernelGGL((k_step<MULTI, DEF, true>), grid, block, h->lds, h->stream, h->S, h->cap, n_steps,            \
+                               actions_dev, obs_dev, reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset,       \
+                               (unsigned long long)h->steps_done);                                                           \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((k_step<MULTI, DEF>), grid, block, h->lds, h->stream, h->S, h->cap, n_steps, actions_dev,     \
+                               obs_dev, reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset,                    \
+                               (unsigned long long)h->steps_done);                                                           \
+    } while (0)
         if (n_steps == 1) {
             // bit 1: record-first staging (memoised rejections never load their ring), throughput regime only
             const char *lz = getenv("MESHENV_LAZY");
@@ -1654,7 +1672,7 @@ int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float
         h->err = "meshenv_step_actor: env and actor must be on the same device and stream (meshenv_set_stream / meshenv_actor_set_stream)";
         return MESHENV_E_STATE;
     }
-    const bool fusable = h->group == 16 && !h->spec && h->default_params &&
+    const bool fusable = h->group == 16 && !h->spec && h->default_params && !h->front_moved &&
                          h->timing == 0 && !h->reselect_pending && group_actor_lds_bytes(h->cap) <= 160 * 1024;
     if (!fusable) {   // same results by two launches (other batch sizes / ring lengths, timing armed, the
                       // step after meshenv_smooth whose parked re-selection changes the observation the policy reads)
@@ -1744,7 +1762,7 @@ int meshenv_step_actor_multi(MeshEnv *h, MeshActor *a, int T, float *actions_dev
         return MESHENV_E_STATE;
     }
     const size_t n = (size_t)h->n_envs;
-    const bool fusable = h->group == 16 && !h->spec && h->default_params && h->timing == 0 && !h->reselect_pending &&
+    const bool fusable = h->group == 16 && !h->spec && h->default_params && !h->front_moved && h->timing == 0 && !h->reselect_pending &&
                          group_actor_lds_bytes(h->cap) <= 160 * 1024 && !h->S.msg;
     if (!fusable || T == 1) {   // the same results step by step
         for (int t = 0; t < T; t++) {

@@ -1711,7 +1711,9 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
 #ifndef MESHENV_STEP_WAVES_PER_SIMD
 #define MESHENV_STEP_WAVES_PER_SIMD 4
 #endif
-template <bool kMulti, bool kDefaultParams>
+// (kTie: the handle has smoothed a front -- its rings hold vertices off the 1e-4 lattice and half-quantum angles, so the
+// angles take the tie-breaking atan2 of the move() path, csrc/meshenv_geom.h; the host then steps with these instantiations)
+template <bool kMulti, bool kDefaultParams, bool kTie = false>
 __global__ void __launch_bounds__(64, MESHENV_STEP_WAVES_PER_SIMD)
 k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, float *__restrict__ obs_out,
        double *__restrict__ reward, uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
@@ -1720,6 +1722,7 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     extern __shared__ double2 smem[];
     if (kDefaultParams) apply_default_params(S.prm);
     Ctx c;
+    c.tie = kTie;
     carve_lds(c, smem, cap);
     const int env = blockIdx.x;
     const int E = S.n_envs;

@@ -315,6 +315,53 @@ def test_full_size_65536_envs_smooth_pave_with_front_smoother_sampled_oracle_sha
     env.close()
 
 
+def test_steps_after_a_front_smoothing_run_the_tie_breaking_kernel(torch_cuda):
+    """A front smoothing leaves vertices off the 1e-4 lattice, and with them clockwise angles exactly on a rounding boundary
+    (the smoother builds points at tan(q e-4 / 2)): until every env has been reset the handle steps with k_step in its
+    tie-breaking instantiation instead of the CU-group kernel (include/meshenv.h, meshenv_step_kernel).  4 096 envs: which
+    kernel steps before / after / after the reset, and 256 shadowed envs bit-identical to the oracle across the switch."""
+    torch = torch_cuda
+    from oracle.ref_lib import RefBatch, RefEnv
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv, boundary
+    n, S = 4096, 256
+    dom = boundary(0)
+    env = MeshVecEnv([dom], n_envs=n, auto_reset=True, log_capacity=96)
+    L, h = env._L, env._handle
+    pick = np.arange(0, n, n // S)[:S]
+    refs = [RefEnv.from_points(dom, cap_new=96) for _ in pick]
+    batch = RefBatch(refs)
+    idx = torch.from_numpy(pick).cuda()
+    assert np.array_equal(env.reset()[idx].cpu().numpy(), batch.reset())
+    g = torch.Generator(device="cuda"); g.manual_seed(33)
+    lo = torch.tensor([-1.0, 0.2, 0.3], device="cuda"); hi = torch.tensor([1.0, 1.0, 1.2], device="cuda")
+    differing = [0]
+
+    def steps(k):
+        for _ in range(k):
+            a = (lo + (hi - lo) * torch.rand((n, 3), device="cuda", generator=g)).contiguous()
+            o, r, d, c = env.step(a)
+            o_ref, r_ref, d_ref, c_ref = batch.step(a[idx].cpu().numpy(), auto_reset=True, threads=16)
+            assert np.array_equal(d[idx].cpu().numpy(), d_ref) and np.array_equal(c[idx].cpu().numpy(), c_ref)
+            differing[0] += int((o[idx].cpu().numpy() != o_ref.astype(np.float32)).sum())
+
+    assert L.meshenv_step_kernel(h) == 1
+    steps(40)
+    sweeps, _ = env.smooth_pave(iteration=400, interior=False)
+    obs_after = env.obs[idx].cpu().numpy()
+    for j in range(S):
+        code, sw, o_ref = refs[j].smooth_pave_full(400)
+        assert code == 0 and sw == int(sweeps[pick[j]]) and np.array_equal(obs_after[j], o_ref.astype(np.float32)), j
+    assert L.meshenv_step_kernel(h) == 0
+    steps(60)
+    assert differing[0] == 0
+    env.reset()
+    batch.reset()
+    assert L.meshenv_step_kernel(h) == 1
+    steps(10)
+    assert differing[0] == 0
+    env.close()
+
+
 def test_smooth_of_the_archived_episode_equals_smooth_of_the_running_one(torch_cuda):
     """meshenv_smooth_final(which = 1): under auto-reset the finished mesh lives in the archive half of the logs and its
     front is gone with the ring; smooth() only needs the front's membership, which is recovered from the logs.  Two

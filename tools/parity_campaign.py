@@ -104,7 +104,8 @@ if __name__ == "__main__":
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     seed_off = int(sys.argv[sys.argv.index("--seed-offset") + 1]) if "--seed-offset" in sys.argv else 0
     if "--move-only" in sys.argv:
-        mdoms = [boundary(0), boundary(-1), boundary(1), boundary(2)] + [golden_domain(x) for x in ("boundary16_biased_s2", "random1_1_biased_s1", "star_biased_s6")] + [random_domain(7000 + k) for k in range(25)]
+        dom_off = int(sys.argv[sys.argv.index("--domain-offset") + 1]) if "--domain-offset" in sys.argv else 0   # other generated polygons
+        mdoms = [boundary(0), boundary(-1), boundary(1), boundary(2)] + [golden_domain(x) for x in ("boundary16_biased_s2", "random1_1_biased_s1", "star_biased_s6")] + [random_domain(7000 + dom_off + k) for k in range(25)]
         move_campaign("move() x2048 on 32 domains", mdoms, (np.arange(2048) % len(mdoms)).astype(np.int32), int(60 * scale), 105 + seed_off)
         sys.exit(0)
     campaign("boundary0 x4096 uniform", [boundary(0)], np.zeros(4096, np.int32), int(1000 * scale), 101, False)
