@@ -171,10 +171,10 @@ int meshenv_group_size(const MeshEnv *h);
 /* Which single-step kernel meshenv_step launches: 0 = k_step<false> (one wave per workgroup), 1 = k_step_group<G>
  * (checks, workgroup barrier, updates dealt over the SIMDs), 2 = k_step_spec<G> (no barrier: an action that survives the
  * cheap exact tests is extracted speculatively by an idle wavefront while its checks finish).
- * After a front smoothing (meshenv_smooth with interior = 0, or a meshenv_move that went through smooth_pave) and until the
- * next reset of ALL envs the answer is 0: rings may then hold vertices off the 1e-4 lattice, whose clockwise angles can sit
- * exactly on a rounding boundary, and steps run k_step in the instantiation that decides those like the reference's libm
- * (meshenv_atan2_exact). */
+ * 3 = k_step<false, ., true>: after a front smoothing (meshenv_smooth with interior = 0, or a meshenv_move that went through
+ * smooth_pave) and until the next reset of ALL envs rings may hold vertices off the 1e-4 lattice, whose clockwise angles
+ * can sit exactly on a rounding boundary; steps then run the one-wave-per-env kernel in the instantiation that decides
+ * those like the reference's libm (meshenv_atan2_exact). */
 int meshenv_step_kernel(const MeshEnv *h);
 /* The smoothing kernels evaluate `x ** 2` like the reference's libm (CPython's float ** 2 is pow(x, 2.0), which glibc does
  * not round correctly: it differs from x * x in 0.085 % of the arguments) through a restatement of glibc's pow

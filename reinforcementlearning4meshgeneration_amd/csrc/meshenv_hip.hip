@@ -784,7 +784,7 @@ int meshenv_set_packed_output(MeshEnv *h, float *msg_dev)
 int meshenv_num_envs(const MeshEnv *h) { return h ? h->n_envs : MESHENV_E_ARG; }
 int meshenv_max_ring(const MeshEnv *h) { return h ? h->max_ring : MESHENV_E_ARG; }
 int meshenv_group_size(const MeshEnv *h) { return h ? h->group : MESHENV_E_ARG; }
-int meshenv_step_kernel(const MeshEnv *h) { return h ? (h->group > 1 && !h->front_moved ? (h->spec ? 2 : 1) : 0) : MESHENV_E_ARG; }
+int meshenv_step_kernel(const MeshEnv *h) { return h ? (h->front_moved ? 3 : (h->group > 1 ? (h->spec ? 2 : 1) : 0)) : MESHENV_E_ARG; }
 int meshenv_libm_exact(const MeshEnv *h) { return h ? h->libm_exact : MESHENV_E_ARG; }
 int meshenv_atan2_exact(void) { return atan_host().mode == 2 ? 1 : 0; }
 

@@ -152,8 +152,6 @@ class MeshVecEnv:
         torch = self._torch
         self.max_ring = self._L.meshenv_max_ring(self._handle)
         self.group_size = self._L.meshenv_group_size(self._handle)
-        self.step_kernel = {0: "meshenv::k_step<false, true>", 1: f"meshenv::k_step_group<{self.group_size}, true>",
-                            2: f"meshenv::k_step_spec<{self.group_size}, true>"}[self._L.meshenv_step_kernel(self._handle)]
         n = self.num_envs
         self.obs = torch.zeros((n, OBS_DIM), dtype=torch.float32, device=self.device)
         self.terminal_obs = torch.zeros((n, OBS_DIM), dtype=torch.float32, device=self.device)
@@ -344,6 +342,15 @@ class MeshVecEnv:
                                   self.done.data_ptr(), self.complete.data_ptr(), self.move_code.data_ptr())
         self._check(rc, "meshenv_move")
         return self.obs, self.done, self.complete, self.move_code
+
+    @property
+    def step_kernel(self) -> str:
+        """Name (as rocprofv3 prints it) of the kernel the next step() launches, from meshenv_step_kernel: the CU-group kernel
+        for batches of one workgroup per CU, the one-wave-per-env kernel otherwise -- in its tie-breaking instantiation
+        (`k_step<false, true, true>`) between a front smoothing and the next reset of all envs."""
+        return {0: "meshenv::k_step<false, true, false>", 1: f"meshenv::k_step_group<{self.group_size}, true>",
+                2: f"meshenv::k_step_spec<{self.group_size}, true>",
+                3: "meshenv::k_step<false, true, true>"}[self._L.meshenv_step_kernel(self._handle)]
 
     @property
     def libm_exact(self) -> int:

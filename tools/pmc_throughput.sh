@@ -14,7 +14,7 @@ python3 - $out <<'PY'
 import csv, glob, json, sys
 from collections import defaultdict
 out = sys.argv[1]
-K = "k_step<false, true>"
+K = "k_step<false, true, false>"
 agg = defaultdict(lambda: defaultdict(float))
 for sub in ("sq", "sq2", "fetch", "write"):
     for f in glob.glob(f"{out}/{sub}/**/*counter_collection.csv", recursive=True):

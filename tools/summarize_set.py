@@ -23,7 +23,9 @@ def last_json(path):
 
 def counters(d, sub):
     per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))   # kernel -> counter -> dispatch -> sum
-    for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True)
+    # gpurun merges into gpurun_out/ without deleting: an earlier run's files may sit beside this one's -- newest only
+    for f in sorted(files, key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             per[r["Kernel_Name"]][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     return {k: {c: sum(v.values()) / len(v) for c, v in cs.items()} for k, cs in per.items()}
@@ -31,7 +33,7 @@ def counters(d, sub):
 
 for key in sorted(os.listdir(src)):
     d = os.path.join(src, key)
-    stats = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]
     if not stats:
         print(key, "no kernel trace"); continue
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_{key}_kernel_stats.csv"))
