@@ -118,7 +118,19 @@ __device__ __forceinline__ int spin_until_nonzero(volatile int *w)
 }
 
 // Python list index wrap for i in [-n, 2n)
-__device__ __forceinline__ int wrapi(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
+// i mod n for i in [-n, 2n): as unsigned numbers exactly one of i, i + n, i - n lies in [0, n) and it is the smallest
+// (the other two are "negative", i.e. huge, or >= n) -- two adds and one v_min3_u32 instead of two compares, two adds and
+// two selects.
+__device__ __forceinline__ int wrapi(int i, int n)
+{
+#ifdef MESHENV_WRAPI_SELECT
+    return i < 0 ? i + n : (i >= n ? i - n : i);
+#else
+    const unsigned a = (unsigned)i, b = (unsigned)(i + n), c = (unsigned)(i - n);
+    const unsigned m = a < b ? a : b;
+    return (int)(m < c ? m : c);
+#endif
+}
 
 __host__ __device__ __forceinline__ size_t lds_bytes_for(int cap)
 {
@@ -1708,8 +1720,10 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
 // (kMulti = true, meshenv_rollout).  Two instantiations on purpose: inside the multi-step loop the compiler hoists
 // every lane predicate and table of the step body into the loop preheader (hundreds of instructions and SGPR
 // spills that a single step would pay for nothing).
+// (five waves per SIMD = at most 96 VGPRs: with four the allocator drifts to 97 and the 65 536-env launch loses 7 % to the
+// lost wave; tools/ab_all.sh)
 #ifndef MESHENV_STEP_WAVES_PER_SIMD
-#define MESHENV_STEP_WAVES_PER_SIMD 4
+#define MESHENV_STEP_WAVES_PER_SIMD 5
 #endif
 // (kTie: the handle has smoothed a front -- its rings hold vertices off the 1e-4 lattice and half-quantum angles, so the
 // angles take the tie-breaking atan2 of the move() path, csrc/meshenv_geom.h; the host then steps with these instantiations)
