@@ -130,6 +130,20 @@ __device__ MESHENV_NOINLINE SinCos sincos_nc(double a)
     return r;
 }
 __device__ MESHENV_NOINLINE double sin_nc(double a) { return sin(a); }
+// sin / cos of the angles the step kernels form themselves (all in [0, 3 pi]): the small-range form of csrc/meshenv_libm.h,
+// a sixth of ocml's instructions
+__device__ MESHENV_NOINLINE SinCos sincos_small_nc(double a)
+{
+#ifdef MESHENV_OCML_SINCOS   // (A/B builds only)
+    return sincos_nc(a);
+#else
+    const SinCosD r = sincos_small(a);
+    SinCos o;
+    o.s = r.s;
+    o.c = r.c;
+    return o;
+#endif
+}
 
 // ---------------------------------------------------------------------------------- primitives
 // Point2D.distance_to, C:17-18.  (The reference's `** 2` is libm pow(x, 2.0), which differs from x*x by

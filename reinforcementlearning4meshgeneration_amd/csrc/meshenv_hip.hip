@@ -1437,6 +1437,8 @@ __global__ void k_selftest(int what, int n, const double *in, double *out, int l
         const double t = atan2_glibc(in[2 * i], in[2 * i + 1], g_atan_cij, ok);
         out[i] = ok ? t : __builtin_nan("");
     } else if (what == 14) out[i] = atan2_cr(in[2 * i], in[2 * i + 1]);
+    else if (what == 15) out[i] = sincos_small_nc(in[i]).s;   // against the host libm's sin / cos: within an ulp
+    else if (what == 16) out[i] = sincos_small_nc(in[i]).c;
 }
 
 int meshenv_selftest(int device, int what, int n, int in_per_item, const double *in_host, double *out_host)

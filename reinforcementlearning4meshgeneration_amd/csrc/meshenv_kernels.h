@@ -494,7 +494,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     double sj = 0.0, cj = 1.0;
     if (lane < 5) {  // one exec-masked call; the argument is a select chain
         const double arg = lane == 0 ? theta / 2 : lane == 1 ? rot : lane == 2 ? thd : lane == 3 ? bq.q_ang0 : bq.q_ang2;
-        const SinCos sc = sincos_nc(arg);
+        const SinCos sc = sincos_small_nc(arg);
         sj = sc.s;
         cj = sc.c;
     }
@@ -1493,7 +1493,7 @@ __device__ __forceinline__ double reward_on_helper(Ctx &c, const DevState &S, co
     const double e_reward = uniform_f64(sqrt(q1e * (amn / amx)));
     const double half01 = uniform_f64(0.5 * e0 * e1), half23 = uniform_f64(0.5 * e2 * e3);
     double sj = 0.0;
-    if (lane < 2) sj = sincos_nc(lane == 0 ? ang0 : ang2).s;  // the sincos of stage B
+    if (lane < 2) sj = sincos_small_nc(lane == 0 ? ang0 : ang2).s;  // the sincos of stage B
     const double mesh_area = uniform_f64(half01 * lane_f64(sj, 0) + half23 * lane_f64(sj, 1));
     // speed penalty, B:434-450
     const DomConst &dc = S.dom[dom];
