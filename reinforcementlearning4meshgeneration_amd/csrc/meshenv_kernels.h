@@ -64,6 +64,7 @@ struct Scratch {
     double tmp2[8];     // quad edge / diagonal lengths
     float robs[18];     // observation rows before the final float32 rounding
     int ipad[2];
+    unsigned long long red[6];   // first-wins minima of the observation scan (find_next_state, LDS atomics)
 #ifdef MESHENV_STAMPS
     unsigned long long stamps[16];
 #endif
@@ -614,8 +615,28 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     // ---- reductions: first-wins minima as packed (value bits, order) keys, one interleaved DPP scan
     u64 rk = (u64)__double_as_longlong(rbest), mk = (u64)__double_as_longlong(m_d);
     const u64 my_rk = rk;
+#ifdef MESHENV_DPP_REDUCTIONS
     wave_min5_u64(k0, k1, k2, rk, mk);
     const unsigned ro = wave_min_u32(my_rk == rk ? (unsigned)rord : 0xffffffffu);  // earliest among equal hits
+#else
+    // Only the few lanes whose vertex lies inside the fan (or whose edge the bisector hits) hold anything but the identity:
+    // they take the minima with LDS atomics -- five DPP reductions of 64-bit keys are ~170 instructions on the one
+    // wavefront whose issue slot the whole extraction runs on, this is ~40 and three LDS round trips.
+    u64 *red = c.sc->red;
+    const u64 rk_init = (u64)__double_as_longlong(1.0), mk_init = (u64)__double_as_longlong(kInf);
+    if (lane < 6) red[lane] = lane < 3 ? kSlotInit : (lane == 3 ? rk_init : (lane == 4 ? mk_init : ~0ULL));
+    wave_sync();
+    if (k0 != kSlotInit) atomicMin(&red[0], k0);
+    if (k1 != kSlotInit) atomicMin(&red[1], k1);
+    if (k2 != kSlotInit) atomicMin(&red[2], k2);
+    if (rk != rk_init) atomicMin(&red[3], rk);
+    if (mk != mk_init) atomicMin(&red[4], mk);
+    wave_sync();
+    k0 = red[0]; k1 = red[1]; k2 = red[2]; rk = red[3]; mk = red[4];
+    if (my_rk == rk && rk != rk_init) atomicMin(&red[5], (u64)(unsigned)rord);   // earliest among equal hits
+    wave_sync();
+    const unsigned ro = (unsigned)red[5];
+#endif
     rbest = __longlong_as_double((long long)rk);
     m_d = __longlong_as_double((long long)mk);
     const float s0 = __uint_as_float((unsigned)(k0 >> 32)), s1 = __uint_as_float((unsigned)(k1 >> 32)), s2 = __uint_as_float((unsigned)(k2 >> 32));
