@@ -18,9 +18,12 @@ ARCH = "gfx950"
 # -mllvm -disable-machine-licm: the kernels' loops run once or twice (64-vertex chunks of a ring); hoisting constant
 # materialisation out of them only lengthens live ranges (k_step<false>: 94 -> 89 VGPRs, 86 -> 78 spilled SGPRs;
 # measured +1..3 % in the throughput workloads, neutral on the headline: profiles/r03_ab_all.log).
+# -mllvm -amdgpu-atomic-optimizer-strategy=None: the LDS atomics of the observation scan (find_next_state) have one to
+# three active lanes; the optimiser's wave reduction in front of them is the very DPP sequence they replace
+# (headline 14.58 -> 14.42 us, 65 536 envs +1 %, rollout +2 %; tools/ab_all.sh).
 HIPCC_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
                "-fno-fast-math", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-               "-mllvm", "-disable-machine-licm"]
+               "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def hipcc_path() -> str:

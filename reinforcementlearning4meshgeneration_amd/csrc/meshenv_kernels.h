@@ -2147,6 +2147,14 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     if (active && (tid & 63) == 0) {
         unsigned long long *o = S.dbg + (size_t)env * 16;
         o[0] = dbg_t0; o[1] = dbg_t1; o[2] = dbg_t2; o[3] = (unsigned long long)pending; o[4] = 0; o[5] = 0;
+#ifdef MESHENV_DBG_P1SET   // two of the check's stage stamps per build (tools/phase1_stages.py): 0 = decode, ring pass; 1 = quad, intersections
+        {
+            Ctx cs;
+            carve_lds(cs, (char *)smem + (size_t)wave * env_bytes, cap);
+            o[4] = cs.sc->stamps[MESHENV_DBG_P1SET ? 4 : 1];
+            o[5] = cs.sc->stamps[MESHENV_DBG_P1SET ? 5 : 2];
+        }
+#endif
         if (!pending) o[15] = 0;
     }
 #endif
