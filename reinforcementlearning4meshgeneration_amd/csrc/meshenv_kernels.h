@@ -1741,6 +1741,34 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
 // (kMulti = true, meshenv_rollout).  Two instantiations on purpose: inside the multi-step loop the compiler hoists
 // every lane predicate and table of the step body into the loop preheader (hundreds of instructions and SGPR
 // spills that a single step would pay for nothing).
+// The argument list of k_step as the kernel-argument segment lays it out.  The one-step instantiation reads what its
+// epilogue needs (output pointers, the ring arrays for the write-back) from there a second time, behind an opaque copy of
+// the segment pointer, instead of keeping ~20 scalar registers alive -- or spilled to VGPR lanes -- across the whole step.
+struct KStepArgs {
+    DevState S;
+    int cap, n_steps;
+    const float *actions;
+    float *obs_out;
+    double *reward;
+    uint8_t *done, *complete;
+    float *term_obs;
+    int auto_reset;
+    unsigned long long step0;
+};
+template <bool kDefaultParams>
+__device__ __forceinline__ KStepArgs late_kstep_args()
+{
+    typedef const __attribute__((address_space(4))) unsigned long long *qptr;
+    qptr q = (qptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));   // not before this point
+    static_assert(sizeof(KStepArgs) % 8 == 0, "whole quadwords");
+    union { KStepArgs a; unsigned long long w[sizeof(KStepArgs) / 8]; } u;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(KStepArgs) / 8; i++) u.w[i] = q[i];
+    if (kDefaultParams) apply_default_params(u.a.S.prm);
+    return u.a;
+}
+
 // (five waves per SIMD = at most 96 VGPRs: with four the allocator drifts to 97 and the 65 536-env launch loses 7 % to the
 // lost wave; tools/ab_all.sh)
 #ifndef MESHENV_STEP_WAVES_PER_SIMD
@@ -1834,6 +1862,36 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
             env_apply(c, S, d);
         }
         const StepResult r = env_finish(c, S.prm, d);
+#if !defined(MESHENV_STAMPS) && !defined(MESHENV_NO_LATE_ARGS)
+        if (!kMulti) {   // one step per launch: the epilogue on freshly read arguments (see late_kstep_args)
+            const KStepArgs L = late_kstep_args<kDefaultParams>();
+            const bool l_auto = (L.auto_reset & 1) != 0;   // (bits 1, 2 of the argument select the staging mode)
+            if (r.valid || (r.done && l_auto)) {
+                const unsigned long long next = L.step0 + 1ULL;
+                k.sum_n += (unsigned long long)n_before * (next - k.last_change);
+                k.last_change = next;
+                if (r.valid) { k.valid += 1ULL; k.sum_n_valid += (unsigned long long)n_before; }
+                k_dirty = true;
+            }
+            if (c.lane == 0) {
+                L.reward[env] = r.reward;
+                L.done[env] = (uint8_t)r.done;
+                L.complete[env] = (uint8_t)r.complete;
+            }
+            if (r.done) {
+                if (L.term_obs && c.lane < kObsDim) L.term_obs[(size_t)env * kObsDim + c.lane] = c.obs;
+                if (l_auto) reset_from_domain(c, L.S);
+            }
+            if (c.lane < kObsDim) L.obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
+            if (L.S.msg && c.lane < 21) {
+                const float v = c.lane < kObsDim ? c.obs : (c.lane == 18 ? (float)r.reward : (c.lane == 19 ? (float)r.done : (float)r.complete));
+                L.S.msg[(size_t)env * 21 + c.lane] = v;
+            }
+            store_env(c, L.S);
+            if (k_dirty && c.lane == 0) L.S.cnt[env] = k;
+            return;
+        }
+#endif
 #ifdef MESHENV_STAMPS
         if (r.valid) st_valid += 1;
 #else
