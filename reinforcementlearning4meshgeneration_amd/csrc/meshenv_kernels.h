@@ -2083,16 +2083,39 @@ __device__ __forceinline__ StepOuts late_outs(const int tstep = 0, const int n_e
     return o;
 }
 
+// The DevState at the head of the kernel-argument segment (GroupArgs and every argument block built on it), read again behind
+// an opaque copy of the segment pointer: the write-back of a step needs the ring arrays, the record and counter arrays and
+// the domain table, none of which the checks or the update in between touch -- re-reading them costs two scalar loads,
+// holding them costs scalar registers (or VGPR lanes) on every path.  prm comes from the caller's copy (literals).
+__device__ __forceinline__ DevState late_state(const DevState &S, KernArgPtr ka_in = nullptr)
+{
+#ifdef MESHENV_NO_LATE_ARGS
+    return S;
+#else
+    typedef const __attribute__((address_space(4))) unsigned long long *qptr;
+    qptr q = (qptr)(ka_in ? ka_in : (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr());
+    asm volatile("" : "+s"(q));   // not before this point
+    constexpr unsigned kWords = offsetof(DevState, prm) / 8;
+    static_assert(offsetof(DevState, prm) % 8 == 0, "whole quadwords before prm");
+    union { DevState s; unsigned long long w[sizeof(DevState) / 8]; } u;
+    u.s = S;
+#pragma unroll
+    for (unsigned i = 0; i < kWords; i++) u.w[i] = q[i];
+    return u.s;
+#endif
+}
+
 // reward / flags / observation of one finished step, auto-reset, state write-back, work counters
 // (helper_done != nullptr: the reward of this valid step is written by a helper wavefront, which also reads the ring:
 // an auto-reset waits for it before it overwrites the ring)
-__device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S, const Decision &d, const EnvCounters &cnt0,
+__device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S_in, const Decision &d, const EnvCounters &cnt0,
                                                  int n_before, int auto_reset, unsigned long long step0,
                                                  volatile int *helper_done = nullptr, float *actor_row = nullptr, const int tstep = 0,
                                                  KernArgPtr ka = nullptr)
 {
-    const StepResult r = env_finish(c, S.prm, d);
+    const StepResult r = env_finish(c, S_in.prm, d);
     const int env = c.env;
+    const DevState S = late_state(S_in, ka);
     const StepOuts o = late_outs(tstep, S.n_envs, ka);
     float *__restrict__ obs_out = o.obs_out;
     double *__restrict__ reward = o.reward;
@@ -2290,7 +2313,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
         if (c.n > 5) {  // not the end of the episode: the ring is final, write it back here (off the update wave's path)
             c.env = henv;
             c.base = (size_t)henv * S.cap;
-            store_ring(c, S);
+            store_ring(c, late_state(S, ka));
         }
         if (c.lane == 0) {
             *(volatile int *)&h.helper_done = 1;
