@@ -1826,7 +1826,15 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
     const bool light = !kMulti && (auto_reset & 4) != 0;
     auto_reset &= 1;
 #ifndef MESHENV_STAMPS
-    const EnvCounters cnt0 = S.cnt[env];  // requested with the rest of the state: no round trip at the end
+    // (requested with the rest of the state in the T-step instantiation: no round trip at the end; the one-step
+    // instantiation reads them in its epilogue, when the step changed the ring)
+#if defined(MESHENV_EARLY_COUNTERS) || defined(MESHENV_NO_LATE_ARGS)
+    const EnvCounters cnt0 = S.cnt[env];
+#else
+    EnvCounters cnt0;
+    cnt0.last_change = 0; cnt0.valid = 0; cnt0.sum_n = 0; cnt0.sum_n_valid = 0;
+    if (kMulti) cnt0 = S.cnt[env];
+#endif
 #endif
     if (light) load_env(c, S, env, false);
     else load_env(c, S, env);
@@ -1867,6 +1875,9 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
             const KStepArgs L = late_kstep_args<kDefaultParams>();
             const bool l_auto = (L.auto_reset & 1) != 0;   // (bits 1, 2 of the argument select the staging mode)
             if (r.valid || (r.done && l_auto)) {
+#ifndef MESHENV_EARLY_COUNTERS
+                k = L.S.cnt[env];   // (the work counters too: one step in nine needs them, and only here)
+#endif
                 const unsigned long long next = L.step0 + 1ULL;
                 k.sum_n += (unsigned long long)n_before * (next - k.last_change);
                 k.last_change = next;
