@@ -2122,7 +2122,7 @@ __device__ __forceinline__ DevState late_state(const DevState &S, KernArgPtr ka_
 __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S_in, const Decision &d, const EnvCounters &cnt0,
                                                  int n_before, int auto_reset, unsigned long long step0,
                                                  volatile int *helper_done = nullptr, float *actor_row = nullptr, const int tstep = 0,
-                                                 KernArgPtr ka = nullptr)
+                                                 KernArgPtr ka = nullptr, const bool cnt_late = false)
 {
     const StepResult r = env_finish(c, S_in.prm, d);
     const int env = c.env;
@@ -2159,7 +2159,9 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S_in, c
     }
     store_env(c, S, has_helper && !r.done);
     if ((r.valid || (r.done && auto_reset)) && c.lane == 0) {  // the ring length changes after this step
-        EnvCounters k = cnt0;
+        // (cnt_late: a rejected step of the CU-group kernel -- its counters only move when the episode is truncated, so
+        // they are read here instead of being held, unused, through the checks of every wave)
+        EnvCounters k = cnt_late ? S.cnt[env] : cnt0;
         k.sum_n += (unsigned long long)n_before * (step0 + 1ULL - k.last_change);
         k.last_change = step0 + 1ULL;
         if (r.valid) { k.valid += 1ULL; k.sum_n_valid += (unsigned long long)n_before; }
@@ -2206,12 +2208,19 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
         carve_lds(c, (char *)smem + (size_t)wave * env_bytes, cap);
         const float *a = actions + (size_t)env * 3;
         const float a0 = a[0], a1 = a[1], a2 = a[2];
+#ifdef MESHENV_EARLY_COUNTERS
         const EnvCounters cnt0 = S.cnt[env];
+        constexpr bool kCntLate = false;
+#else
+        EnvCounters cnt0;
+        cnt0.last_change = 0; cnt0.valid = 0; cnt0.sum_n = 0; cnt0.sum_n_valid = 0;
+        constexpr bool kCntLate = true;
+#endif
         load_env(c, S, env, true, tid_in >= 0 ? (tid & 63) : -1);
         const int n_before = c.n;
         Decision d = env_check(c, S, a0, a1, a2, false, false, 0.0, 0.0, 0.5, nullptr, true);
         if (!d.ok) {
-            finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0, nullptr, actor_in ? actor_in + wave * 132 : nullptr, tstep, ka);
+            finish_and_store(c, S, d, cnt0, n_before, auto_reset, A.step0, nullptr, actor_in ? actor_in + wave * 132 : nullptr, tstep, ka, kCntLate);
         } else {
             pending = 1;
             if (c.lane == 0) {
@@ -2219,7 +2228,9 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
                 h.env = env; h.n = c.n; h.ref = c.ref; h.n_elem = c.n_elem; h.failed = c.failed; h.n_new = c.n_new;
                 h.counter = c.counter; h.status = c.status; h.dom = c.dom;
                 h.bl = c.bl; h.area = c.area; h.ct = c.ct; h.st = c.st;
+#ifdef MESHENV_EARLY_COUNTERS
                 h.cnt0 = cnt0;
+#endif
                 h.d = d;
                 h.upd_done = 0;
                 h.helper_done = 0;
@@ -2353,7 +2364,11 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     d.p0 = uniform_i32(d.p0); d.p1 = uniform_i32(d.p1); d.p2 = uniform_i32(d.p2); d.p3 = uniform_i32(d.p3);
     d.t0 = uniform_i32(d.t0); d.t1 = uniform_i32(d.t1); d.lo = uniform_i32(d.lo); d.hi = uniform_i32(d.hi);
     d.ok = 1;
+#ifdef MESHENV_EARLY_COUNTERS
     const EnvCounters cnt0 = h.cnt0;
+#else
+    const EnvCounters cnt0 = S.cnt[c.env];   // requested now, used after the update: the round trip hides behind it
+#endif
     const int n_before = c.n;
     env_apply(c, S, d, helpers ? &h.upd_done : nullptr);
 #ifdef MESHENV_STAMPS
