@@ -1922,10 +1922,31 @@ k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, floa
         }
         last_reward = r.reward; last_done = r.done; last_complete = r.complete;
         if (r.done) {
+#if !defined(MESHENV_STAMPS) && !defined(MESHENV_NO_LATE_ARGS)
+            // (T steps per launch: the end of an episode -- one step in ~25 -- reads what it needs afresh; the per-step
+            // stores keep their pointers: re-reading those on every step of one wave's serial chain cost 11 %)
+            const KStepArgs L = late_kstep_args<kDefaultParams>();
+            if (L.term_obs && c.lane < kObsDim) L.term_obs[(size_t)env * kObsDim + c.lane] = c.obs;
+            if (L.auto_reset & 1) reset_from_domain(c, L.S);
+#else
             if (term_obs && c.lane < kObsDim) term_obs[(size_t)env * kObsDim + c.lane] = c.obs;
             if (auto_reset) reset_from_domain(c, S);
+#endif
         }
     }
+#if !defined(MESHENV_STAMPS) && !defined(MESHENV_NO_LATE_ARGS)
+    {   // the epilogue of the T-step launch on freshly read arguments (the one-step instantiation has returned above)
+        const KStepArgs L = late_kstep_args<kDefaultParams>();
+        if (c.lane < kObsDim) L.obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
+        if (L.S.msg && c.lane < 21) {
+            const float v = c.lane < kObsDim ? c.obs : (c.lane == 18 ? (float)last_reward : (c.lane == 19 ? (float)last_done : (float)last_complete));
+            L.S.msg[(size_t)env * 21 + c.lane] = v;
+        }
+        store_env(c, L.S);
+        if (k_dirty && c.lane == 0) L.S.cnt[env] = k;
+        return;
+    }
+#endif
     if (c.lane < kObsDim) obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
     if (S.msg && c.lane < 21) {
         const float v = c.lane < kObsDim ? c.obs : (c.lane == 18 ? (float)last_reward : (c.lane == 19 ? (float)last_done : (float)last_complete));
