@@ -1141,14 +1141,12 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         const dim3 grid(h->n_envs), block(64);
 #define MESHENV_LAUNCH_STEP(MULTI, DEF)                                                                                      \
     do {                                                                                                                     \
-        if (h->front_moved)                                                                                                  \
-            hipLaunchKernelGGL((k_step<MULTI, DEF, true>), grid, block, h->lds, h->stream, h->S, h->cap, n_steps,            \
-                               actions_dev, obs_dev, reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset,       \
-                               (unsigned long long)h->steps_done);                                                           \
-        else                                                                                                                 \
-            hipLaunchKernelGGL((k_step<MULTI, DEF>), grid, block, h->lds, h->stream, h->S, h->cap, n_steps, actions_dev,     \
-                               obs_dev, reward_dev, done_dev, complete_dev, terminal_obs_dev, auto_reset,                    \
-                               (unsigned long long)h->steps_done);                                                           \
+        KStepArgs ka;                                                                                                        \
+        ka.S = h->S; ka.cap = h->cap; ka.n_steps = n_steps; ka.actions = actions_dev; ka.obs_out = obs_dev;                  \
+        ka.reward = reward_dev; ka.done = done_dev; ka.complete = complete_dev; ka.term_obs = terminal_obs_dev;              \
+        ka.auto_reset = auto_reset; ka.step0 = (unsigned long long)h->steps_done;                                            \
+        if (h->front_moved) hipLaunchKernelGGL((k_step<MULTI, DEF, true>), grid, block, h->lds, h->stream, ka);              \
+        else hipLaunchKernelGGL((k_step<MULTI, DEF>), grid, block, h->lds, h->stream, ka);                                   \
     } while (0)
         if (n_steps == 1) {
             // bit 1: record-first staging (memoised rejections never load their ring), throughput regime only

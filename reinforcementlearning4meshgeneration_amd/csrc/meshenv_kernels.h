@@ -1741,7 +1741,7 @@ __global__ void __launch_bounds__(64) k_reset(DevState S, int cap, const uint8_t
 // (kMulti = true, meshenv_rollout).  Two instantiations on purpose: inside the multi-step loop the compiler hoists
 // every lane predicate and table of the step body into the loop preheader (hundreds of instructions and SGPR
 // spills that a single step would pay for nothing).
-// The argument list of k_step as the kernel-argument segment lays it out.  The one-step instantiation reads what its
+// The single by-value argument of k_step.  The one-step instantiation reads what its
 // epilogue needs (output pointers, the ring arrays for the write-back) from there a second time, behind an opaque copy of
 // the segment pointer, instead of keeping ~20 scalar registers alive -- or spilled to VGPR lanes -- across the whole step.
 struct KStepArgs {
@@ -1778,10 +1778,19 @@ __device__ __forceinline__ KStepArgs late_kstep_args()
 // angles take the tie-breaking atan2 of the move() path, csrc/meshenv_geom.h; the host then steps with these instantiations)
 template <bool kMulti, bool kDefaultParams, bool kTie = false>
 __global__ void __launch_bounds__(64, MESHENV_STEP_WAVES_PER_SIMD)
-k_step(DevState S, int cap, int n_steps, const float *__restrict__ actions, float *__restrict__ obs_out,
-       double *__restrict__ reward, uint8_t *__restrict__ done, uint8_t *__restrict__ complete,
-       float *__restrict__ term_obs, int auto_reset, unsigned long long step0)
+k_step(const KStepArgs A)
 {
+    // (one by-value argument block: its layout IS the kernel-argument segment that late_kstep_args reads again)
+    DevState S = A.S;
+    const int cap = A.cap, n_steps = A.n_steps;
+    const float *__restrict__ actions = A.actions;
+    float *__restrict__ obs_out = A.obs_out;
+    double *__restrict__ reward = A.reward;
+    uint8_t *__restrict__ done = A.done, *__restrict__ complete = A.complete;
+    float *__restrict__ term_obs = A.term_obs;
+    (void)term_obs;   // (only the diagnostic / no-late-argument builds read it from here)
+    int auto_reset = A.auto_reset;
+    const unsigned long long step0 = A.step0;
     extern __shared__ double2 smem[];
     if (kDefaultParams) apply_default_params(S.prm);
     Ctx c;
