@@ -131,6 +131,9 @@ struct MeshEnv {
     bool spec = false;    // single-step kernel = k_step_spec (speculative extraction, no workgroup barrier)
     int group = 1;        // environments (wavefronts) per workgroup of the single-step kernel
     size_t group_lds = 0;
+    int2 *env_lds = nullptr;   // ragged LDS packing of the CU-group kernel: [n_envs] (byte offset in the workgroup, ring slots), or null
+    int ho_off = 0;            // ragged: offset of the hand-over blocks
+    std::vector<int2> env_lds_host;
     std::vector<int32_t> dom_off_host, env_dom_host;
     std::vector<void *> allocs;
     std::string err;
@@ -368,19 +371,43 @@ static int create_impl(int device, int n_domains, const int32_t *dom_offsets_hos
         for (int g : {16, 8, 4})
             if (g <= want && group_lds_bytes(cap, g) <= 150 * 1024) { G = g; break; }
         if (!force && (G < 8 || n_envs > n_cu * G)) G = 1;  // LDS forced a smaller group: more than one workgroup per CU
+        // Ragged packing: sixteen rings of the LONGEST stride do not fit, sixteen rings of their own lengths may (mixed
+        // d1 / d2 / d3: 120 / 196 / 272 vertices -> 135 KB instead of 197 KB).  One workgroup per CU as in the uniform case.
+        if (G == 1 && want == 16 && n_envs <= n_cu * 16 && group_lds_bytes(cap, 16) > 150 * 1024) {
+            std::vector<int2> pack((size_t)n_envs);
+            size_t worst = 0;
+            for (int w0 = 0; w0 < n_envs; w0 += 16) {
+                size_t off = 0;
+                for (int e = w0; e < w0 + 16 && e < n_envs; e++) {
+                    const int d = env_domain_host[e];
+                    const int n0 = dom_offsets_host[d + 1] - dom_offsets_host[d];
+                    const int cap_e = (n0 + 15) / 16 * 16;
+                    pack[(size_t)e] = make_int2((int)off, cap_e);
+                    off += lds_bytes_for(cap_e);
+                }
+                worst = off > worst ? off : worst;
+            }
+            worst = (worst + 31) / 32 * 32;
+            if (worst + 16 * sizeof(Handoff) <= (size_t)kLdsCap) {   // one workgroup per CU: the whole 160 KB may go to it
+                G = 16;
+                h->env_lds_host.swap(pack);
+                h->ho_off = (int)worst;
+            }
+        }
         MeshEnvParams def;
         meshenv_default_params(&def);
         h->default_params = prm.radius == def.radius && prm.max_ref_angle == def.max_ref_angle && prm.key_lambda == def.key_lambda &&
                             prm.min_degree == def.min_degree && prm.max_degree == def.max_degree &&
                             prm.same_point_eps == def.same_point_eps && prm.ray_length == def.ray_length;
         if (!h->default_params) G = 1;  // the group kernels exist with literal (default) geometry constants only
+        if (!h->default_params) h->env_lds_host.clear();
         h->group = G;
-        h->group_lds = group_lds_bytes(cap, G);
+        h->group_lds = h->env_lds_host.empty() ? group_lds_bytes(cap, G) : (size_t)h->ho_off + 16 * sizeof(Handoff);
         // The speculative form of the CU-group kernel (k_step_spec: two ring buffers per env, no workgroup barrier) is
         // opt-in, MESHENV_SPEC=1: measured on MI355X at 4096 x boundary() it takes 16.7 us per launch against 15.5 us
         // for the barrier + deal form (rocprofv3; DESIGN.md section 5 says why), so the default stays k_step_group.
         const char *spec_env = getenv("MESHENV_SPEC");
-        h->spec = (G == 16 || G == 8) && spec_lds_bytes(cap, G) <= 150 * 1024 && spec_env && atoi(spec_env) == 1;
+        h->spec = h->env_lds_host.empty() && (G == 16 || G == 8) && spec_lds_bytes(cap, G) <= 150 * 1024 && spec_env && atoi(spec_env) == 1;
         if (h->spec) {
             h->group_lds = spec_lds_bytes(cap, G);
             if (h->group_lds > 64 * 1024) {
@@ -428,6 +455,10 @@ static int create_impl(int device, int n_domains, const int32_t *dom_offsets_hos
     CREATE_TRY(dev_alloc(h, &S.scal, (size_t)n_envs));
     CREATE_TRY(dev_alloc(h, &S.cnt, (size_t)n_envs));
     CREATE_TRY(dev_alloc(h, &S.obs_cache, (size_t)n_envs * kObsDim));
+    if (!h->env_lds_host.empty()) {
+        CREATE_TRY(dev_alloc(h, &h->env_lds, (size_t)n_envs));
+        CREATE_HIP(hipMemcpy(h->env_lds, h->env_lds_host.data(), sizeof(int2) * (size_t)n_envs, hipMemcpyHostToDevice));
+    }
     if (prm.log_capacity > 0) {
         CREATE_TRY(dev_alloc(h, &K.log_quads, (size_t)n_envs * 2 * prm.log_capacity * 4));
         CREATE_TRY(dev_alloc(h, &K.log_vxy, (size_t)n_envs * 2 * prm.log_capacity));
@@ -1132,6 +1163,9 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         A.step0 = (unsigned long long)h->steps_done;
         A.cap = h->cap;
         A.auto_reset = auto_reset;
+        A.env_lds = h->env_lds;
+        A.ho_off = h->ho_off;
+        A.pad = 0;
         if (h->spec && G == 16) hipLaunchKernelGGL((k_step_spec<16, true>), grid, block, h->group_lds, h->stream, A);
         else if (h->spec && G == 8) hipLaunchKernelGGL((k_step_spec<8, true>), grid, block, h->group_lds, h->stream, A);
         else if (G == 16) hipLaunchKernelGGL((k_step_group<16, true>), grid, block, h->group_lds, h->stream, A);
@@ -1672,7 +1706,7 @@ int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float
         h->err = "meshenv_step_actor: env and actor must be on the same device and stream (meshenv_set_stream / meshenv_actor_set_stream)";
         return MESHENV_E_STATE;
     }
-    const bool fusable = h->group == 16 && !h->spec && h->default_params && !h->front_moved &&
+    const bool fusable = h->group == 16 && !h->spec && h->default_params && !h->front_moved && !h->env_lds &&
                          h->timing == 0 && !h->reselect_pending && group_actor_lds_bytes(h->cap) <= 160 * 1024;
     if (!fusable) {   // same results by two launches (other batch sizes / ring lengths, timing armed, the
                       // step after meshenv_smooth whose parked re-selection changes the observation the policy reads)
@@ -1695,6 +1729,7 @@ int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float
     GA.g.actions = actions_dev;
     GA.g.step0 = (unsigned long long)h->steps_done;
     GA.g.cap = h->cap;
+    GA.g.env_lds = nullptr; GA.g.ho_off = 0; GA.g.pad = 0;
     GA.g.auto_reset = auto_reset;
     GA.W = a->W;
     GA.actions_next = actions_next_dev;
@@ -1762,7 +1797,7 @@ int meshenv_step_actor_multi(MeshEnv *h, MeshActor *a, int T, float *actions_dev
         return MESHENV_E_STATE;
     }
     const size_t n = (size_t)h->n_envs;
-    const bool fusable = h->group == 16 && !h->spec && h->default_params && !h->front_moved && h->timing == 0 && !h->reselect_pending &&
+    const bool fusable = h->group == 16 && !h->spec && h->default_params && !h->front_moved && !h->env_lds && h->timing == 0 && !h->reselect_pending &&
                          group_actor_lds_bytes(h->cap) <= 160 * 1024 && !h->S.msg;
     if (!fusable || T == 1) {   // the same results step by step
         for (int t = 0; t < T; t++) {
@@ -1787,6 +1822,7 @@ int meshenv_step_actor_multi(MeshEnv *h, MeshActor *a, int T, float *actions_dev
     GA.g.actions = actions_dev;
     GA.g.step0 = (unsigned long long)h->steps_done;
     GA.g.cap = h->cap;
+    GA.g.env_lds = nullptr; GA.g.ho_off = 0; GA.g.pad = 0;
     GA.g.auto_reset = auto_reset;
     GA.W = a->W;
     GA.eps_out = eps_out_dev;

@@ -205,21 +205,24 @@ __device__ __forceinline__ EnvLoad load_env_issue(const DevState &S, int env, co
     return L;
 }
 
+// (lds_cap > 0: the ring slots this env's LDS region holds, when it is smaller than the HBM stride S.cap -- the CU-group
+// kernel packs the rings of mixed domains by their own lengths, see step_group_body; 0 = S.cap)
 __device__ __forceinline__ void load_env_commit(Ctx &c, const DevState &S, int env, const EnvLoad &L, const bool with_keys = true,
-                                                const int lane_in = -1)
+                                                const int lane_in = -1, const int lds_cap = 0)
 {
     const int lane = lane_in >= 0 ? lane_in : lane_id();
     c.lane = lane;
     c.env = env;
     c.base = (size_t)env * S.cap;
     const EnvScalars &s = L.s;
-    const int first = S.cap < 64 ? S.cap : 64;
+    const int lcap = lds_cap > 0 ? lds_cap : S.cap;
+    const int first = lcap < 64 ? lcap : 64;
     const double2 *gxy = S.ring_xy + c.base;
     const int32_t *gid = S.ring_id + c.base;
     const double *gkey = S.ring_key + c.base;
     const int32_t *gst = S.ring_stamp + c.base;
     const unsigned ul = (unsigned)lane;
-    const bool second = S.cap > 64 && (int)(64u + ul) < S.cap;
+    const bool second = lcap > 64 && (int)(64u + ul) < lcap;
     c.obs = L.obs;
     c.n = uniform_i32(s.n); c.ref = uniform_i32(s.ref); c.n_elem = uniform_i32(s.n_elem);
     c.failed = uniform_i32(s.failed); c.n_new = uniform_i32(s.n_new); c.counter = uniform_i32(s.counter);
@@ -253,10 +256,11 @@ __device__ __forceinline__ void load_env_commit(Ctx &c, const DevState &S, int e
     wave_sync();
 }
 
-__device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env, const bool with_keys = true, const int lane_in = -1)
+__device__ __forceinline__ void load_env(Ctx &c, const DevState &S, int env, const bool with_keys = true, const int lane_in = -1,
+                                         const int lds_cap = 0)
 {
     const EnvLoad L = load_env_issue(S, env, with_keys, lane_in);
-    load_env_commit(c, S, env, L, with_keys, lane_in);
+    load_env_commit(c, S, env, L, with_keys, lane_in, lds_cap);
 }
 
 // the candidate keys and stamps of a ring staged without them (load_env(.., false)), before an extraction
@@ -2064,7 +2068,9 @@ struct alignas(32) Handoff {
     int simd;   // hardware SIMD the checking wave runs on
     int upd_done;     // phase 2: the update wave has written the post-update ring (the helper may read it)
     int helper_done;  // phase 2: the helper has finished reading the ring (an auto-reset may overwrite it)
-    int env, n, ref, n_elem, failed, n_new, counter, status, dom, pad[3];
+    int env, n, ref, n_elem, failed, n_new, counter, status, dom;
+    int lds_off, lds_cap;   // ragged packing: byte offset and slot count of the env's LDS region (step_group_body)
+    int pad;
     double bl, area, ct, st;
     EnvCounters cnt0;
     Decision d;
@@ -2093,6 +2099,12 @@ struct GroupArgs {
     unsigned long long step0;  // index of this step since the handle was created (lazy work counters)
     int cap;
     int auto_reset;
+    // Ragged LDS packing (nullptr = every env owns lds_bytes_for(cap) bytes): [n_envs] (byte offset of the env's region in
+    // its workgroup's LDS, ring slots it holds).  A batch of mixed domains -- d1 / d2 / d3: 120 / 196 / 272 vertices --
+    // does not fit sixteen rings of the LONGEST stride into one CU's LDS, but it does fit sixteen rings of their own lengths.
+    const int2 *env_lds;
+    int ho_off;   // ragged: byte offset of the hand-over blocks (behind the largest workgroup's rings)
+    int pad;
 };
 
 // tstep / n: the T-steps-per-launch closed loop (csrc/meshenv_fused.h) writes step t of the launch into slice t of
@@ -2223,7 +2235,8 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     if (kDefaultParams) apply_default_params(S.prm);
     const int wave = uniform_i32(tid >> 6);  // wave-uniform by construction: keeps env and every address derived from it in SGPRs
     const size_t env_bytes = lds_bytes_for(cap);
-    Handoff *ho = (Handoff *)((char *)smem + (size_t)G * env_bytes);
+    const int2 *env_lds = A.env_lds;   // ragged packing (nullptr: uniform regions of env_bytes)
+    Handoff *ho = (Handoff *)((char *)smem + (env_lds ? (size_t)A.ho_off : (size_t)G * env_bytes));
     const int env = blockIdx.x * G + wave;
     const bool active = env < S.n_envs;
     SPEC_TIME(env, 8);
@@ -2235,7 +2248,13 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
 #endif
     if (active) {
         Ctx c;
-        carve_lds(c, (char *)smem + (size_t)wave * env_bytes, cap);
+        int my_off = (int)((size_t)wave * env_bytes), my_cap = cap;
+        if (env_lds) {   // wave-uniform: one scalar load, requested with the state
+            const int2 e = env_lds[env];
+            my_off = uniform_i32(e.x);
+            my_cap = uniform_i32(e.y);
+        }
+        carve_lds(c, (char *)smem + my_off, my_cap);
         const float *a = actions + (size_t)env * 3;
         const float a0 = a[0], a1 = a[1], a2 = a[2];
 #ifdef MESHENV_EARLY_COUNTERS
@@ -2246,7 +2265,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
         cnt0.last_change = 0; cnt0.valid = 0; cnt0.sum_n = 0; cnt0.sum_n_valid = 0;
         constexpr bool kCntLate = true;
 #endif
-        load_env(c, S, env, true, tid_in >= 0 ? (tid & 63) : -1);
+        load_env(c, S, env, true, tid_in >= 0 ? (tid & 63) : -1, env_lds ? my_cap : 0);
         const int n_before = c.n;
         Decision d = env_check(c, S, a0, a1, a2, false, false, 0.0, 0.0, 0.5, nullptr, true);
         if (!d.ok) {
@@ -2257,6 +2276,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
                 Handoff &h = ho[wave];
                 h.env = env; h.n = c.n; h.ref = c.ref; h.n_elem = c.n_elem; h.failed = c.failed; h.n_new = c.n_new;
                 h.counter = c.counter; h.status = c.status; h.dom = c.dom;
+                h.lds_off = my_off; h.lds_cap = my_cap;
                 h.bl = c.bl; h.area = c.area; h.ct = c.ct; h.st = c.st;
 #ifdef MESHENV_EARLY_COUNTERS
                 h.cnt0 = cnt0;
@@ -2283,7 +2303,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
 #ifdef MESHENV_DBG_P1SET   // two of the check's stage stamps per build (tools/phase1_stages.py): 0 = decode, ring pass; 1 = quad, intersections
         {
             Ctx cs;
-            carve_lds(cs, (char *)smem + (size_t)wave * env_bytes, cap);
+            carve_lds(cs, (char *)smem + (env_lds ? env_lds[env].x : (int)((size_t)wave * env_bytes)), env_lds ? env_lds[env].y : cap);
             o[4] = cs.sc->stamps[MESHENV_DBG_P1SET ? 4 : 1];
             o[5] = cs.sc->stamps[MESHENV_DBG_P1SET ? 5 : 2];
         }
@@ -2353,8 +2373,9 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     if (hsrc >= 0) {
         // ---- phase 2, helper: the reward of env ho[hsrc]
         Ctx c;
-        carve_lds(c, (char *)smem + (size_t)hsrc * env_bytes, cap);
         Handoff &h = ho[hsrc];
+        if (env_lds) carve_lds(c, (char *)smem + uniform_i32(h.lds_off), uniform_i32(h.lds_cap));
+        else carve_lds(c, (char *)smem + (size_t)hsrc * env_bytes, cap);
         c.lane = tid & 63;
         Decision d = h.d;
         d.index = uniform_i32(d.index); d.new_vertex = uniform_i32(d.new_vertex);
@@ -2378,8 +2399,9 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
 
     // ---- phase 2: the update of env ho[src], in place in its LDS region
     Ctx c;
-    carve_lds(c, (char *)smem + (size_t)src * env_bytes, cap);
     Handoff &h = ho[src];
+    if (env_lds) carve_lds(c, (char *)smem + uniform_i32(h.lds_off), uniform_i32(h.lds_cap));
+    else carve_lds(c, (char *)smem + (size_t)src * env_bytes, cap);
     c.lane = tid & 63;
     c.env = uniform_i32(h.env);
     c.base = (size_t)c.env * S.cap;

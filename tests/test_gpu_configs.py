@@ -111,6 +111,12 @@ def test_config4_mixed_d1_d2_d3_one_gpu_share(torch_cuda):
     print("config4 mixed:", st)
     assert st["valid"] > 0.1 * n * T
     assert st["obs_mismatch"] <= 1e-6 * st["obs_total"]
+    # sixteen 272-slot rings do not fit one CU's LDS; sixteen rings of their own lengths (120 / 196 / 272) do: the batch
+    # steps with the CU-group kernel, its LDS packed by ring length (csrc/meshenv_kernels.h, GroupArgs::env_lds)
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv
+    probe = MeshVecEnv(doms, env_domain=env_domain)
+    assert probe.step_kernel == "meshenv::k_step_group<16, true>"
+    probe.close()
 
 
 def test_config5_one_random_domain_per_env_8192(torch_cuda):

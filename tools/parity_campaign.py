@@ -112,6 +112,8 @@ if __name__ == "__main__":
     campaign("boundary0 x4096 biased", [boundary(0)], np.zeros(4096, np.int32), int(1000 * scale), 102, True)
     big = [golden_domain(x) for x in ("boundary16_biased_s2", "boundary15_biased_s5", "test1_biased_s42", "dolphine3_biased_s0", "random1_1_biased_s1", "star_biased_s6")]
     campaign("6 shipped domains x2046 biased", big, (np.arange(2046) % 6).astype(np.int32), int(300 * scale), 103, True)
+    # the same six rings (120 .. 272 vertices), sixteen per workgroup: the CU-group kernel with its LDS packed by ring length
+    campaign("6 shipped domains x4096 biased (ragged CU-group kernel)", big, (np.arange(4096) % 6).astype(np.int32), int(150 * scale), 106, True)
     rnd = [random_domain(5000 + k) for k in range(1024)]
     campaign("1024 random polygons x4096 biased", rnd, (np.arange(4096) % 1024).astype(np.int32), int(400 * scale), 104, True)
     mdoms = [boundary(0), boundary(-1), boundary(1), boundary(2)] + big + [random_domain(7000 + k) for k in range(22)]
