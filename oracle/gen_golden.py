@@ -31,7 +31,7 @@ TRACES = [
     ("test1_biased_s42", "test1", "biased", 42, 300),
     ("dolphine3_biased_s0", "dolphine3", "biased", 0, 300),
     ("random1_1_biased_s1", "random1_1", "biased", 1, 300),
-    ("basic_biased_s4", "basic", "biased", 4, 300),
+    ("basic_biased_s4", "basic", "biased", 4, 40),       # 5-vertex ring: every step ends the episode at B:141-143 (no extraction)
     ("star_biased_s6", "star", "biased", 6, 300),
 ]
 
@@ -288,6 +288,155 @@ def main_move(only=None):
               f"through smooth_pave {int(tr['smoothed'].sum())}, with NumPy zero-divisor warnings {int((tr['warned'] > 0).sum())}")
 
 
+# (fixture name, domain, seed, T): accepted find_same_point extractions (B:165-175 -> M:623-629)
+SAMEPOINT_TRACES = [
+    ("boundary0_samepoint", "boundary0", 5, 260),
+    ("star_samepoint", "star", 6, 220),
+    ("random1_1_samepoint", "random1_1", 7, 220),
+]
+
+
+def samepoint_trace(dom, seed, T):
+    """A rule-0 action whose decoded point lies within 0.001 of a ring vertex while the rule -1 quad [i-1, i, i+1, i+2] is
+    acceptable: the reference reuses that quad with `rule = 0` kept (B:165-175), so update_boundary takes its
+    "no new vertex" branch (M:623-629) and the reward bookkeeping is rule 0's.  The reference env cannot be copied or
+    undone, so every probe replays the episode's action history on a fresh env.  Between such extractions the stream is
+    the biased random one; near-vertex points that the reference rejects (rule -1 quad invalid, point outside) are kept
+    in the stream too."""
+    pts = H.domain_points(dom)
+
+    def replay(hist):
+        e = H.make_env(pts)
+        e.reset()
+        for a in hist:
+            e.step(a)
+        return e
+
+    env = H.make_env(pts)
+    env.reset()
+    rng = np.random.default_rng(seed)
+    hist, actions = [], []
+    offsets = [(0, 0), (4, 3), (-4, 3), (4, -3), (-4, -3), (7, 0), (0, 7), (-7, 0), (0, -7), (9, 4), (-2, -9), (0.4, 0.3)]
+    accepted = 0
+    while len(actions) < T:
+        a = None
+        p = replay(hist)
+        nb = len(p.generated_meshes)
+        p.step(np.array([-1.0, 0.5, 0.5], np.float32))
+        rule_m1_ok = len(p.generated_meshes) > nb
+        ring = env.updated_boundary.vertices
+        i, n = ring.index(env.current_point_environment.reference_point), len(ring)
+        want = rng.random()
+        if rule_m1_ok and want < 0.7:
+            ks = [i + 2, i, i + 1, i - 1, i + int(rng.integers(3, max(4, n - 2)))]
+            rng.shuffle(ks)
+            for k in ks:
+                v = ring[k % n]
+                order = rng.permutation(len(offsets))
+                for o in order:
+                    dx, dy = offsets[o][0] * 1e-4, offsets[o][1] * 1e-4
+                    c = action_for_target(env, float(rng.choice([0.0, 0.3, -0.45, 0.49])), (v.x + dx, v.y + dy))
+                    if not (abs(c[1]) <= 1.5 and 0 <= c[2] <= 1.5):
+                        continue
+                    q = replay(hist)
+                    qb, qv = len(q.generated_meshes), len(q.boundary.vertices)
+                    q.step(c)
+                    if len(q.generated_meshes) > qb and len(q.boundary.vertices) == qv:
+                        a = c
+                        accepted += 1
+                        break
+                if a is not None:
+                    break
+        elif want > 0.9:
+            # a near-vertex point without the guarantee (rejected when the rule -1 quad is invalid or the point is outside)
+            v = ring[int(rng.integers(n))]
+            dx, dy = offsets[int(rng.integers(len(offsets)))]
+            c = action_for_target(env, 0.0, (v.x + dx * 1e-4, v.y + dy * 1e-4))
+            if abs(c[1]) <= 1.5 and 0 <= c[2] <= 1.5:
+                a = c
+        if a is None:
+            a = H.biased_actions(int(rng.integers(1 << 30)), 1)[0]
+        actions.append(a)
+        hist.append(a)
+        _, _, done, _ = env.step(a)
+        if done:
+            env.reset()
+            hist = []
+    return pts, np.stack(actions).astype(np.float32), accepted
+
+
+def main_samepoint():
+    for name, dom, seed, T in SAMEPOINT_TRACES:
+        pts, acts, accepted = samepoint_trace(dom, seed, T)
+        tr = H.record_trace(pts, acts)
+        hits = int(((tr["valid"] == 1) & (np.abs(acts[:, 0]) < 0.5) & np.isnan(tr["new_xy"][:, 0])).sum())
+        assert hits == accepted, (hits, accepted)
+        save(name, tr)
+        print(f"  {name}: {hits} rule-0 extractions without a new vertex (accepted find_same_point)")
+
+
+# (fixture name, domain, seed, T, p_valid): streams steered towards accepted extractions (several whole episodes each)
+GUIDED_TRACES = [
+    ("half_wheel_guided_s4", "half_wheel", 4, 160, 0.8),
+    ("basic1_guided_s9", "basic1", 9, 260, 0.8),
+    ("boundary0_guided_s3", "boundary0", 3, 260, 0.85),
+]
+
+
+def guided_trace(dom, seed, T, p_valid):
+    """With probability p_valid the next action is one the reference accepts at the current state -- found by trying
+    rule -1, rule +1 and jittered parallelogram-completion points on a replay of the episode's history (the env cannot
+    be copied) -- otherwise a biased random one.  Gives fixtures whose steps are mostly extractions."""
+    pts = H.domain_points(dom)
+
+    def accepted(hist, a):
+        e = H.make_env(pts)
+        e.reset()
+        for h in hist:
+            e.step(h)
+        nb = len(e.generated_meshes)
+        e.step(a)
+        return len(e.generated_meshes) > nb
+
+    env = H.make_env(pts)
+    env.reset()
+    rng = np.random.default_rng(seed)
+    hist, actions = [], []
+    while len(actions) < T:
+        a = None
+        if rng.random() < p_valid:
+            pe = env.current_point_environment
+            ref, right, left = pe.neighbors[3], pe.neighbors[4], pe.neighbors[2]
+            cands = [np.array([float(rng.uniform(-1, -0.5)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(0, 1.5))], np.float32),
+                     np.array([float(rng.uniform(0.5, 1)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(0, 1.5))], np.float32)]
+            for _ in range(4):
+                tx = right.x + left.x - ref.x + float(rng.integers(-3000, 3001)) * 1e-4 * pe.base_length
+                ty = right.y + left.y - ref.y + float(rng.integers(-3000, 3001)) * 1e-4 * pe.base_length
+                cands.append(action_for_target(env, float(rng.uniform(-0.49, 0.49)), (tx, ty)))
+            for _ in range(10):     # the sub-box the biased stream draws from
+                cands.append(np.array([float(rng.uniform(-0.49, 0.49)), float(rng.uniform(0.2, 1.0)), float(rng.uniform(0.3, 1.2))], np.float32))
+            for k in rng.permutation(len(cands)):
+                c = cands[k]
+                if abs(c[1]) <= 1.5 and 0 <= c[2] <= 1.5 and accepted(hist, c):
+                    a = c
+                    break
+        if a is None:
+            a = H.biased_actions(int(rng.integers(1 << 30)), 1)[0]
+        actions.append(a)
+        hist.append(a)
+        _, _, done, _ = env.step(a)
+        if done:
+            env.reset()
+            hist = []
+    return pts, np.stack(actions).astype(np.float32)
+
+
+def main_guided():
+    for name, dom, seed, T, p_valid in GUIDED_TRACES:
+        pts, acts = guided_trace(dom, seed, T, p_valid)
+        save(name, H.record_trace(pts, acts))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--smooth-only" in sys.argv:
@@ -297,6 +446,13 @@ def main():
         return
     if "--quality-only" in sys.argv:
         quality_fixture()
+        return
+    if "--samepoint-only" in sys.argv:
+        main_samepoint()
+        return
+    if "--guided-only" in sys.argv:
+        main_guided()
+        save("basic_biased_s4", H.record_trace(H.domain_points("basic"), H.biased_actions(4, 40)))
         return
     if "--move-only" in sys.argv:
         main_move(only=[a for a in sys.argv[1:] if a.startswith("move_")])
@@ -309,6 +465,8 @@ def main():
         save(name, H.record_trace(pts, acts))
     pts, acts = targeted_trace()
     save("boundary0_targeted", H.record_trace(pts, acts))
+    main_samepoint()
+    main_guided()
     main_move()
     main_smooth()
     main_final_smooth()

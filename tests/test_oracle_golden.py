@@ -63,6 +63,12 @@ def test_golden_covers_edge_cases():
     assert any(t["obs_none"].any() for t in trs), "no None observation"
     assert any((t["ring_len"] == 4).any() for t in trs) and any((t["ring_len"] == 5).any() for t in trs)
     assert any((~np.isnan(t["new_xy"][:, 0])).any() for t in trs)
+    # accepted find_same_point (rl/boundary_env.py:165-175 -> general/mesh.py:623-629): a rule-0 action within 0.001 of a
+    # ring vertex reuses the rule -1 quad -- a valid step with |a0| < 0.5 and no new vertex
+    same = [int(((t["valid"] == 1) & (np.abs(t["actions"][:, 0]) < 0.5) & np.isnan(t["new_xy"][:, 0])).sum()) for t in trs]
+    assert sum(same) >= 5 and sum(1 for s in same if s > 0) >= 2, same
+    # a near-vertex point that is NOT accepted as well (hit, rule -1 quad invalid): boundary0_targeted steps 7 and 11
+    assert all(int(t["valid"].sum()) > 0 or t["domain_xy"].shape[0] <= 5 for t in trs), "a fixture without any extraction"
 
 
 # ------------------------------------------------------------------------------------------------ move() API (8f row 4)
