@@ -98,7 +98,11 @@ def test_cu_group_kernel_matches_reference_trace(torch_cuda, name, n_envs):
     tr = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
     pts = [tuple(p) for p in tr["domain_xy"]]
     env = _mk([pts], n_envs=n_envs, auto_reset=False)
-    assert "k_step_group" in env.step_kernel, env.step_kernel
+    if len(pts) <= 64:
+        assert f"k_step_group<{16 if n_envs == 4096 else 8}" in env.step_kernel, env.step_kernel
+    elif "k_step_group" not in env.step_kernel:     # sixteen 224-slot rings exceed one CU's LDS: one wave per workgroup
+        env.close()
+        pytest.skip(f"{name} at {n_envs} envs runs on {env.step_kernel}")
     obs = env.reset().cpu().numpy()
     assert (obs == tr["reset_obs"][None]).all()
     probe = [0, 1, 15, 16, n_envs // 2 + 3, n_envs - 1]
