@@ -406,6 +406,19 @@ int meshenv_get_last_episode(MeshEnv *h, int env, int32_t *quads_host, int cap_e
 int meshenv_element_quality(MeshEnv *h, int which, double *elem_dev, double *stats_dev, int32_t *count_dev);
 
 /*
+ * MeshGeneration.get_quality(element, index) (general/mesh.py:1728-1747; called as env.get_quality(env.generated_meshes[i], 4)
+ * by rl/baselines/testbed.py:194-197, and by generate_meshes_canvas, general/mesh.py:1770-1778, for the labels of
+ * save_meshes) for n arbitrary quads, on the device:
+ *   quad_xy_dev [n][4][2] float64, vertices in Mesh.vertices order; out_dev [n] float64
+ *   index 0 = Mesh.get_quality() 'default', 1 = compute_element_quality (general/mesh.py:1714-1726), 3 = 'stretch',
+ *         4 = 'robust', 5 = 'strong' (general/components.py:863-930).
+ * Indices 2 and 6 add compute_ele_boundary_quality of the ring right after the extraction; that value exists only
+ * inside the step that extracted the element (it is the step's reward term) -> MESHENV_E_ARG.
+ * Stream-ordered on the handle's stream.
+ */
+int meshenv_quad_quality(MeshEnv *h, int n, const double *quad_xy_dev, int index, double *out_dev);
+
+/*
  * Work counters since creation (roofline accounting), summed over envs:
  *   out_host[0] env steps executed, [1] valid extractions, [2] sum of ring lengths over all steps,
  *   [3] sum of ring lengths over valid steps.

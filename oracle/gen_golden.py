@@ -437,6 +437,43 @@ def main_guided():
         save(name, H.record_trace(pts, acts))
 
 
+def plot_fixture():
+    """PNG files the reference's save_meshes writes (general/mesh.py:1785-1792) for the first completed episode of the
+    boundary0_biased_s1 stream, with the calls its callers make: the evaluation callback's (rl/baselines/CustomizeCallback.py:
+    131-133: indexing=True, style='k-', dpi=30), testbed's (rl/baselines/testbed.py:189-191: quality=False, type=4, style='k-';
+    dpi lowered to 40 to keep the fixture small) and a labelled one (quality=True, indexing=True, type=4).  Also
+    get_quality(element, index) of every element for the indices that are functions of the quad (0, 1, 3, 4, 5).  The
+    images depend on the matplotlib version (3.x Agg rasteriser): the fixture records it."""
+    import tempfile
+    import matplotlib
+    pts = H.domain_points("boundary0")
+    acts = H.biased_actions(1, 700)
+    env = H.make_env(pts)
+    env.reset()
+    for t in range(len(acts)):
+        _, _, done, info = env.step(acts[t])
+        if done and info["is_complete"]:
+            break
+        if done:
+            env.reset()
+    table = {id(v): k for k, v in enumerate(env.boundary.vertices)}
+    quads = np.array([[table[id(v)] for v in m.vertices] for m in env.generated_meshes], np.int32)
+    vxy = np.array([[float(v.x), float(v.y)] for v in env.boundary.vertices], np.float64)
+    out = dict(trace="boundary0_biased_s1", step=np.int32(t), quads=quads, vertex_xy=vxy, n0=np.int32(len(pts)),
+               matplotlib_version=np.array(matplotlib.__version__),
+               quality_index=np.array([0, 1, 3, 4, 5], np.int32),
+               quality=np.array([[env.get_quality(m, k) for k in (0, 1, 3, 4, 5)] for m in env.generated_meshes], np.float64))
+    calls = {"callback": dict(indexing=True, style='k-', dpi=30),
+             "testbed": dict(quality=False, type=4, indexing=False, style='k-', dpi=40),
+             "labelled": dict(quality=True, indexing=True, type=4, dpi=40)}
+    for key, kw in calls.items():
+        with tempfile.NamedTemporaryFile("rb", suffix=".png") as f:
+            env.save_meshes(f.name, meshes=env.generated_meshes, **kw)
+            out["png_" + key] = np.frombuffer(open(f.name, "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(OUT, "plot_boundary0_biased_s1.npz"), **out)
+    print(f"plot fixture: step {t}, {len(quads)} elements, PNG bytes {[len(out['png_' + k]) for k in calls]}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--smooth-only" in sys.argv:
@@ -446,6 +483,7 @@ def main():
         return
     if "--quality-only" in sys.argv:
         quality_fixture()
+        plot_fixture()
         return
     if "--samepoint-only" in sys.argv:
         main_samepoint()
@@ -459,6 +497,7 @@ def main():
         return
     export_fixture()
     quality_fixture()
+    plot_fixture()
     for name, dom, kind, seed, T in TRACES:
         pts = H.domain_points(dom)
         acts = (H.uniform_actions if kind == "uniform" else H.biased_actions)(seed, T)

@@ -1654,6 +1654,44 @@ void meshenv_ref_element_quality(const double *xy, double *out)
     }
 }
 
+/* MeshGeneration.get_quality(element, index), M:1728-1747, for the indices that depend on the quad alone:
+ * 0 'default' (C:864-869), 1 compute_element_quality (M:1714-1726: sqrt(q1 q2) of get_quality_3, C:952-972),
+ * 3 'stretch', 4 'robust', 5 'strong' (C:907-930).  NaN for any other index. */
+double meshenv_ref_quad_quality(const double *xy, int index)
+{
+    double rec[8];
+    if (index == 0 || index == 3 || index == 4) {
+        meshenv_ref_element_quality(xy, rec);
+        return index == 0 ? rec[7] : (index == 3 ? rec[3] : rec[5]);
+    }
+    if (index != 1 && index != 5) return NAN;
+    P2 m[4];
+    for (int i = 0; i < 4; i++) { m[i].x = xy[2 * i]; m[i].y = xy[2 * i + 1]; }
+    double e[4], ang[4];
+    for (int i = 0; i < 4; i++) {
+        e[i] = dist(m[i], m[(i + 3) % 4]);
+        ang[i] = cw(m[i], m[(i + 1) % 4], m[(i + 3) % 4]);
+    }
+    double area = 0.5 * e[0] * e[1] * sin(ang[0]) + 0.5 * e[2] * e[3] * sin(ang[2]); /* compute_area, C:935-950 */
+    double q1 = 0;
+    if (area > 0) { /* get_quality_3, C:952-961 */
+        double product = 1;
+        for (int i = 0; i < 4; i++) product *= pow(e[i] / sqrt(area), sqrt(area) - e[i] > 0 ? 1 : -1);
+        q1 = pow(product, 1.0 / 4);
+    }
+    double ap = 1;
+    for (int i = 0; i < 4; i++) ap *= 1 - (fabs(ang[i] * (180.0 / PI) - 90) / 90); /* math.degrees(x) = x * (180 / pi) */
+    double q2 = ap < 0 ? 0 : pow(ap, 1.0 / 4);
+    if (index == 1) return pow(q1 * q2, 1.0 / 2);
+    double amin = INFINITY, amax = -INFINITY;
+    for (int i = 0; i < 4; i++) {
+        double a = fabs(ang[i]);
+        if (a < amin) amin = a;
+        if (a > amax) amax = a;
+    }
+    return sqrt(q1 * (amin / amax));
+}
+
 /* DumpQualityStats (Measurement/quality_verdict.py:77-90) prints, per measure, what vtkMeshQuality accumulates over
  * the cells of one mesh: minimum, average, maximum, variance (E[q^2] - E[q]^2) and cardinality.  vals = [n][8]
  * element records, stats = [8][4] = min, mean, max, variance.  (VTK itself is absent: parity unpinned for the

@@ -88,6 +88,7 @@ void meshenv_ref_get_elements(const RefEnv *e, int32_t *quads, double *vertex_xy
  * terminal_obs, if non-NULL, the last obs).  threads > 1 uses OpenMP when compiled with it. */
 /* element quality report (general/components.py:863-933; Measurement/quality_verdict.py:77-90) */
 void meshenv_ref_element_quality(const double *xy /*[4][2]*/, double *out /*[8]*/);
+double meshenv_ref_quad_quality(const double *xy /*[4][2]*/, int index /* 0, 1, 3, 4, 5 */);
 void meshenv_ref_quality_stats(const double *vals /*[n][8]*/, int n, double *stats /*[8][4]*/);
 
 void meshenv_ref_step_batch(RefEnv **envs, int n, const float *actions, float *obs, double *reward,

@@ -82,6 +82,8 @@ def lib():
     L.meshenv_ref_is_cross.argtypes = [_f64p, _f64p, _f64p, _f64p]
     L.meshenv_ref_element_quality.argtypes = [_f64p, _f64p]
     L.meshenv_ref_quality_stats.argtypes = [_f64p, C.c_int, _f64p]
+    L.meshenv_ref_quad_quality.argtypes = [_f64p, C.c_int]
+    L.meshenv_ref_quad_quality.restype = C.c_double
     _lib = L
     return L
 
@@ -101,6 +103,13 @@ def element_quality(quad_xy):
     for i in range(q.shape[0]):
         L.meshenv_ref_element_quality(q[i], out[i])
     return out
+
+
+def quad_quality(quad_xy, index):
+    """quad_xy [M,4,2] -> [M] values of MeshGeneration.get_quality(element, index) for index 0, 1, 3, 4, 5."""
+    L = lib()
+    q = np.ascontiguousarray(quad_xy, np.float64).reshape(-1, 8)
+    return np.array([L.meshenv_ref_quad_quality(q[i], int(index)) for i in range(q.shape[0])], np.float64)
 
 
 def quality_stats(vals):

@@ -45,7 +45,7 @@ EXPORTS = [
     "meshenv_reset_static", "meshenv_move", "meshenv_get_not_valid", "meshenv_step_kernel",
     "meshenv_create_random", "meshenv_get_domain", "meshenv_smooth", "meshenv_smooth_final", "meshenv_get_not_valid_ids", "meshenv_step_actor",
     "meshenv_libm_exact", "meshenv_create_random_density", "meshenv_density_rings",
-    "meshenv_step_actor_multi", "meshenv_extract_samples", "meshenv_atan2_exact",
+    "meshenv_step_actor_multi", "meshenv_extract_samples", "meshenv_atan2_exact", "meshenv_quad_quality",
 ]
 
 
@@ -129,6 +129,8 @@ def load():
     L.meshenv_get_elements.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, i32p, i32p]
     L.meshenv_get_last_episode.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, i32p, i32p, i32p, i32p]
     L.meshenv_element_quality.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.meshenv_quad_quality.argtypes = [vp, C.c_int, vp, C.c_int, vp]
+    L.meshenv_quad_quality.restype = C.c_int
     L.meshenv_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.meshenv_set_timing.argtypes = [vp, C.c_int]
     L.meshenv_kernel_times.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int32)]

@@ -9,9 +9,14 @@
   ``step(action) -> (obs, reward, terminated, truncated, info)`` with
   ``terminated = done and is_complete``, ``truncated = done and not is_complete``.
 
+The class IS a ``gymnasium.Env`` (or a ``gym.Env`` where only gym is installed) whenever one of the two is importable
+(compat.ENV_BASE): Stable-Baselines3 tests ``isinstance(env, gym.Env)`` before it wraps an env in its DummyVecEnv, which
+is what ``SAC('MlpPolicy', env, ...)`` of rl/baselines/RL_Mesh.py:186-197 relies on.  ``api`` defaults to the flavour of
+that base -- Gymnasium 5-tuples under gymnasium (what SB3 >= 2 calls), the reference's 4-tuples otherwise.
+
 It is a one-environment ``MeshVecEnv``: every call is a kernel launch plus a device->host copy, so it exists
 for API compatibility (SB3 wraps it in its own DummyVecEnv) and for evaluation scripts; training at scale
-should hand ``MeshVecEnv`` to SB3 directly.  There is no CPU path: without the GPU library it raises.
+should hand ``SB3MeshVecEnv`` to SB3 directly.  There is no CPU path: without the GPU library it raises.
 """
 from __future__ import annotations
 
@@ -19,23 +24,28 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+from .compat import ENV_BASE, ENV_FLAVOUR
 from .domains import Point, read_polygon
+from .episode_tools import EpisodeTools
 from .vec_env import MeshVecEnv, make_spaces, smoothing_log_capacity
 
 
-class BoudaryEnv:  # the reference's spelling
+class BoudaryEnv(EpisodeTools, ENV_BASE):  # the reference's spelling; rl/boundary_env.py:18 `class BoudaryEnv(MeshGeneration, gym.Env)`
     # log_capacity: elements / generated vertices kept per episode (`generated_meshes`).  Default: the largest value (up to
     # 4096) for which the smoothers' per-env graph still fits one CU's 160 KB of LDS for this domain's ring
     # (vec_env.smoothing_log_capacity: ~2700 for boundary(), ~2400 for the 272-vertex d3 ring); an episode that outgrows it
     # keeps exact counts and rewards, but `generated_meshes` / exports are truncated (a RuntimeWarning says so) and
     # smooth() / smooth_pave() refuse it.
-    metadata = {"render.modes": ["human"]}
+    metadata = {"render.modes": ["human"], "render_modes": ["human"]}
     TYPE_THRESHOLD = 0.3
+    render_mode = None
 
     def __init__(self, boundary: Sequence[Point], experiment_version=None, env_name=None, *, device: int = 0,
-                 api: str = "legacy", log_capacity: Optional[int] = None):
+                 api: Optional[str] = None, log_capacity: Optional[int] = None):
         if hasattr(boundary, "vertices"):  # a reference-style Boundary2D
             boundary = [(v.x, v.y) for v in boundary.vertices]
+        if api is None:
+            api = "gymnasium" if ENV_FLAVOUR == "gymnasium" else "legacy"
         if api not in ("legacy", "gymnasium"):
             raise ValueError("api must be 'legacy' or 'gymnasium'")
         self.api = api
@@ -63,6 +73,8 @@ class BoudaryEnv:  # the reference's spelling
     def reset(self, static=False, *, seed=None, options=None):
         """rl/boundary_env.py:67 `reset(static=False)` (positional, as the legacy callers pass it) and the Gymnasium
         keywords of v2/src/mesh_rl/envs/boundary_env.py:136."""
+        if seed is not None and ENV_FLAVOUR == "gymnasium":
+            super().reset(seed=seed)          # gymnasium.Env.reset seeds self.np_random
         if seed is not None and hasattr(self.action_space, "seed"):
             self.action_space.seed(seed)
         obs = self._vec.reset(static=bool(static)).cpu().numpy()[0].copy()
@@ -177,45 +189,3 @@ class BoudaryEnv:  # the reference's spelling
 
     def close(self):
         self._vec.close()
-
-    # ------------------------------------------------------------------ attributes the reference's callers read
-    @property
-    def generated_meshes(self):
-        """List of quads, each a [4, 2] array of vertex coordinates (rl/boundary_env.py:192)."""
-        quads, vxy = self._vec.get_elements(0)
-        return [vxy[q] for q in quads]
-
-    def get_elements(self):
-        """(quads [n,4] vertex ids, vertices [m,2]) -- what write_generated_elements_2_file consumes."""
-        return self._vec.get_elements(0)
-
-    def write_generated_elements_2_file(self, filename):
-        """Abaqus .inp of the current episode's mesh (general/mesh.py:1842-1864); byte-identical to the reference's file."""
-        from .export import write_inp
-        quads, vxy = self._vec.get_elements(0)
-        write_inp(filename, quads, vxy, self.points)
-
-    def write_2_file(self, filename):
-        """JSON node / element dump (rl/boundary_env.py:648-669)."""
-        from .export import write_2_file
-        quads, vxy = self._vec.get_elements(0)
-        write_2_file(filename, quads, vxy, self.points)
-
-    def element_quality(self):
-        """[n_elem, 8] float64: min / max corner angle (deg), scaled Jacobian, stretch, taper, robust, area, default
-        -- Mesh.get_quality(type) of every generated element (general/components.py:863-950), computed on the GPU."""
-        rec, _, cnt = self._vec.element_quality("current")
-        return rec[0, :int(cnt[0])].cpu().numpy()
-
-    @property
-    def failed_num(self):
-        return self._vec.get_state(0)["failed_num"]
-
-    @property
-    def current_area(self):
-        return self._vec.get_state(0)["current_area"]
-
-    @property
-    def updated_boundary(self):
-        """Current front as an [n, 2] array (ring order)."""
-        return self._vec.get_state(0)["ring_xy"]

@@ -1365,6 +1365,20 @@ int meshenv_element_quality(MeshEnv *h, int which, double *elem_dev, double *sta
     return MESHENV_OK;
 }
 
+int meshenv_quad_quality(MeshEnv *h, int n, const double *quad_xy_dev, int index, double *out_dev)
+{
+    if (!h || n < 0 || (n > 0 && (!quad_xy_dev || !out_dev))) return MESHENV_E_ARG;
+    if (!(index == 0 || index == 1 || index == 3 || index == 4 || index == 5))
+        return fail_arg(h, "meshenv_quad_quality: index must be 0, 1, 3, 4 or 5 (2 and 6 add the boundary term of the extraction "
+                           "step: that value is the step's reward)");
+    if (n == 0) return MESHENV_OK;
+    MESHENV_ON_DEVICE(h);
+    hipLaunchKernelGGL(k_quad_quality, dim3((n + 63) / 64), dim3(64), 0, h->stream, n,
+                       reinterpret_cast<const double2 *>(quad_xy_dev), index, out_dev);
+    HIP_TRY(h, hipGetLastError());
+    return MESHENV_OK;
+}
+
 int meshenv_counters(MeshEnv *h, uint64_t *out_host)
 {
     if (!h || !out_host) return MESHENV_E_ARG;

@@ -165,4 +165,60 @@ k_element_quality(DevState S, int which, double *__restrict__ elem_out, double *
     }
 }
 
+// MeshGeneration.get_quality(element, index) (general/mesh.py:1728-1747) for arbitrary quads, the indices that are a
+// function of the four vertices alone: 0 = Mesh.get_quality() 'default' (C:864-869), 1 = compute_element_quality
+// (M:1714-1726) = sqrt(q1 q2) of Mesh.get_quality_3 (C:952-972), 3 = 'stretch' (C:870-872), 4 = 'robust' (C:873-884),
+// 5 = 'strong' (C:907-930).  One quad per lane: 64 B in, 8 B out.
+__device__ __forceinline__ double quad_quality_index(const P2 *m, int index)
+{
+    const double kPi = 3.141592653589793;
+    double e[4], ang[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        e[i] = dist(m[i], m[(i + 3) & 3]);
+        ang[i] = cw(m[i], m[(i + 1) & 3], m[(i + 3) & 3]);
+    }
+    if (index == 0 || index == 3 || index == 4) {
+        double q[kQualityDim];
+        element_quality(m, q);
+        return index == 0 ? q[7] : (index == 3 ? q[3] : q[5]);
+    }
+    const double area = 0.5 * e[0] * e[1] * sin(ang[0]) + 0.5 * e[2] * e[3] * sin(ang[2]);  // compute_area, C:935-950
+    double q1 = 0.0;  // get_quality_3, C:952-972
+    if (area > 0) {
+        const double ra = sqrt(area);
+        double product = 1.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) product *= (ra - e[i] > 0) ? e[i] / ra : 1.0 / (e[i] / ra);
+        q1 = pow(product, 0.25);
+    }
+    double ap = 1.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) ap *= 1 - (fabs(ang[i] * (180.0 / kPi) - 90) / 90);
+    const double q2 = ap < 0 ? 0.0 : pow(ap, 0.25);
+    if (index == 1) return sqrt(q1 * q2);
+    double amin = kInf, amax = -kInf;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double a = fabs(ang[i]);
+        amin = a < amin ? a : amin;
+        amax = a > amax ? a : amax;
+    }
+    return sqrt(q1 * (amin / amax));  // 'strong'
+}
+
+__global__ void __launch_bounds__(64)
+k_quad_quality(int n, const double2 *__restrict__ quad_xy, int index, double *__restrict__ out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    P2 m[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double2 v = quad_xy[(size_t)i * 4 + k];
+        m[k] = mkp(v.x, v.y);
+    }
+    out[i] = quad_quality_index(m, index);
+}
+
 }  // namespace meshenv

@@ -5,10 +5,12 @@ Two call surfaces over the same engine:
 
 * tensor-native -- ``reset() / step(actions) / rollout(actions)`` take and return CUDA tensors; nothing
   crosses PCIe.  This is what an on-device policy (SAC actor MLP) talks to.
-* SB3 ``VecEnv``-shaped -- ``step_async / step_wait / reset / get_attr / env_method ...`` with numpy arrays,
-  auto-reset, ``infos[k]["terminal_observation"]`` and ``infos[k]["TimeLimit.truncated"]``, i.e. the contract
-  of the reference's vectorised caller (rl/baselines/dummy_vec_env.py:12-125) so Stable-Baselines3 plugs in
-  unchanged.
+* SB3 ``VecEnv`` -- ``SB3MeshVecEnv`` (below) IS a ``stable_baselines3.common.vec_env.VecEnv`` when SB3 is importable:
+  ``reset() / step_async / step_wait / step / get_attr / env_method / envs[k] ...`` with numpy arrays, auto-reset,
+  ``infos[k]["terminal_observation"]`` and ``infos[k]["TimeLimit.truncated"]``, i.e. the contract of the reference's
+  vectorised caller (rl/baselines/dummy_vec_env.py:12-125), so ``SAC('MlpPolicy', SB3MeshVecEnv(...))`` passes SB3's
+  ``isinstance(env, VecEnv)`` test and is not wrapped again.  ``MeshVecEnv`` itself offers the same numpy methods under
+  ``reset_numpy / step_async / step_wait``; its ``reset()`` / ``step()`` are the tensor-native ones.
 
 The Gym surface constants come from rl/boundary_env.py:27 (action Box) and :38-39 (observation Box).
 """
@@ -20,7 +22,9 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import _capi
+from .compat import VEC_ENV_BASE
 from .domains import Point, domain_constants
+from .episode_tools import EpisodeTools
 
 ACTION_LOW = np.array([-1.0, -1.5, 0.0], dtype=np.float32)   # rl/boundary_env.py:27
 ACTION_HIGH = np.array([1.0, 1.5, 1.5], dtype=np.float32)
@@ -162,7 +166,14 @@ class MeshVecEnv:
         self.observation_space, self.action_space = make_spaces()
         self._pending_actions = None
         self._closed = False
-        self.reset()
+        self._envs = None
+        if self._L.meshenv_atan2_exact() == 0:
+            import warnings
+            warnings.warn("meshenv: the running libm's atan2 could not be restated bit for bit (another glibc?): angles that "
+                          "fall on a 1e-4 rounding boundary are decided by a correctly rounded atan2 instead -- results stay "
+                          "within the 1e-5 tolerance of the reference but are no longer guaranteed bit-identical "
+                          "(meshenv_atan2_exact() == 0)", RuntimeWarning, stacklevel=3)
+        self.reset_tensor()
 
     @classmethod
     def from_random(cls, n_envs: int, seed: int, device: int = 0, num_verts: int = 0, edge: float = 0.45,
@@ -313,7 +324,7 @@ class MeshVecEnv:
             pass
 
     # ------------------------------------------------------------------ tensor-native API
-    def reset(self, mask=None, static=False):
+    def reset_tensor(self, mask=None, static=False):
         """reset(static) of rl/boundary_env.py:67-84 for all envs (or those with mask != 0).  Returns obs [n,18].
         static=True is PointEnvironment(static=True): observation entry 1 carries 0 instead of the area ratio."""
         self._bind_stream()
@@ -324,6 +335,8 @@ class MeshVecEnv:
         self._check(self._L.meshenv_reset_static(self._handle, mptr, C.c_void_p(self.obs.data_ptr()), 1 if static else 0),
                     "meshenv_reset_static")
         return self.obs
+
+    reset = reset_tensor      # SB3MeshVecEnv overrides reset() / step() with the VecEnv (numpy) forms
 
     def move(self, points, types):
         """move(new_point, type) of rl/boundary_env.py:265-432 for every env, one launch.
@@ -341,6 +354,7 @@ class MeshVecEnv:
         rc = self._L.meshenv_move(self._handle, points.data_ptr(), types.data_ptr(), self.obs.data_ptr(),
                                   self.done.data_ptr(), self.complete.data_ptr(), self.move_code.data_ptr())
         self._check(rc, "meshenv_move")
+        self._warn_if_libm_inexact()
         return self.obs, self.done, self.complete, self.move_code
 
     @property
@@ -363,6 +377,15 @@ class MeshVecEnv:
         """meshenv_atan2_exact: 1 = angles on a 1e-4 rounding boundary are decided by a validated restatement of the running
         libm's atan2 (so every quantised angle is the reference's), 0 = by a correctly rounded atan2 or ocml's."""
         return int(self._L.meshenv_atan2_exact())
+
+    def _warn_if_libm_inexact(self):
+        if not getattr(self, "_libm_warned", False) and self._L.meshenv_libm_exact(self._handle) == 0:
+            import warnings
+            self._libm_warned = True
+            warnings.warn("meshenv: the smoothing kernels could not validate their restatement of the running libm's "
+                          "pow(x, 2.0) (another glibc, or MESHENV_LIBM_EXACT=0): they square with x * x, which differs from "
+                          "the reference by <= 1 ulp on distances -- smoothed coordinates are within tolerance but no longer "
+                          "guaranteed bit-identical (meshenv_libm_exact() == 0)", RuntimeWarning, stacklevel=3)
 
     def smooth_pave(self, mask=None, iteration: int = 400, interior: bool = True, static: bool = False,
                     which: str = "current"):
@@ -399,6 +422,7 @@ class MeshVecEnv:
                                     self.smooth_sweeps.data_ptr(), self.smooth_diff.data_ptr(),
                                     None if interior else self.obs.data_ptr())
         self._check(rc, "meshenv_smooth")
+        self._warn_if_libm_inexact()
         return self.smooth_sweeps, self.smooth_diff
 
     def smooth(self, mask=None, lr_1: float = 0.999, lr_2: float = 0.999, iteration: int = 400, which: str = "current"):
@@ -423,6 +447,7 @@ class MeshVecEnv:
         rc = self._L.meshenv_smooth_final(self._handle, 1 if which == "last" else 0, mptr, int(iteration), float(lr_1), float(lr_2),
                                           self.smooth_sweeps.data_ptr(), self.smooth_diff.data_ptr())
         self._check(rc, "meshenv_smooth_final")
+        self._warn_if_libm_inexact()
         return self.smooth_sweeps, self.smooth_diff
 
     def get_not_valid(self, env: int) -> np.ndarray:
@@ -445,7 +470,7 @@ class MeshVecEnv:
                                                       last.ctypes.data), "meshenv_get_not_valid_ids")
         return ids[:n.value].copy(), tuple(int(x) for x in last)
 
-    def step(self, actions):
+    def step_tensor(self, actions):
         """One step() of every env.  actions: float32 CUDA tensor [n, 3].
         Returns (obs, reward, done, complete) -- views of buffers that the next call overwrites."""
         t = self._torch
@@ -459,6 +484,8 @@ class MeshVecEnv:
                                   1 if self.auto_reset else 0)
         self._check(rc, "meshenv_step")
         return self.obs, self.reward, self.done, self.complete
+
+    step = step_tensor
 
     def step_actor(self, actor, actions, seed: int = 0, counter: int = 0, sample: bool = True, eps_out=None):
         """One step() of every env AND the policy's actions for the next one, in one launch where the batch runs on the
@@ -668,6 +695,19 @@ class MeshVecEnv:
         self._check(rc, "meshenv_element_quality")
         return rec, stats, counts
 
+    def quad_quality(self, quad_xy, index: int = 0) -> np.ndarray:
+        """MeshGeneration.get_quality(element, index) (general/mesh.py:1728-1747) of m arbitrary quads on the device
+        (meshenv_quad_quality): quad_xy [m, 4, 2] (array or CUDA float64 tensor, Mesh.vertices order); index 0 'default',
+        1 compute_element_quality, 3 'stretch', 4 'robust', 5 'strong'.  Returns a float64 array [m]."""
+        t = self._torch
+        q = t.as_tensor(np.asarray(quad_xy, np.float64) if not t.is_tensor(quad_xy) else quad_xy, dtype=t.float64,
+                        device=self.device).reshape(-1, 4, 2).contiguous()
+        out = t.empty(q.shape[0], dtype=t.float64, device=self.device)
+        self._bind_stream()
+        self._check(self._L.meshenv_quad_quality(self._handle, int(q.shape[0]), q.data_ptr(), int(index), out.data_ptr()),
+                    "meshenv_quad_quality")
+        return out.cpu().numpy()
+
     def quality_report(self, which: str = "last") -> dict:
         """Per measure: the mean over meshes of (average, standard deviation) -- what verdict() prints for a list of
         domains (Measurement/quality_verdict.py:93-105) -- plus the overall range; meshes without elements are skipped."""
@@ -728,7 +768,7 @@ class MeshVecEnv:
         user_msg = getattr(self, "_packed_user", None)   # a caller's own exchange buffer (multi-GPU path) is put back
         self.set_packed_output(msg_dev)
         try:
-            self.step(act_dev)
+            self.step_tensor(act_dev)
         finally:
             self.set_packed_output(user_msg)
         msg_host.copy_(msg_dev, non_blocking=True)
@@ -762,7 +802,7 @@ class MeshVecEnv:
         return infos
 
     def reset_numpy(self):
-        return self.reset().cpu().numpy()
+        return self.reset_tensor().cpu().numpy()
 
     def seed(self, seed=None):
         # step()/reset() of the reference contain no RNG; only the action space sampler is seeded
@@ -770,30 +810,135 @@ class MeshVecEnv:
             self.action_space.seed(seed)
         return [seed] * self.num_envs
 
-    def get_attr(self, attr_name, indices=None):
-        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
-        return [self._env_attr(attr_name, i) for i in idx]
+    @property
+    def envs(self):
+        """Per-env views, indexable like DummyVecEnv.envs (rl/baselines/dummy_vec_env.py:25): ``env.envs[0].generated_meshes``,
+        ``env.envs[0].save_meshes(...)`` of the evaluation callback (rl/baselines/CustomizeCallback.py:131-133)."""
+        if self._envs is None:
+            self._envs = _EnvViews(self)
+        return self._envs
 
-    def _env_attr(self, name, i):
-        if name == "generated_meshes":
-            quads, vxy = self.get_elements(i)
-            return [vxy[q] for q in quads]
-        st = self.get_state(i)
-        if name in st:
-            return st[name]
-        if name in ("observation_space", "action_space"):
-            return getattr(self, name)
-        raise AttributeError(name)
+    def _indices(self, indices):
+        if indices is None:
+            return range(self.num_envs)
+        return [indices] if isinstance(indices, (int, np.integer)) else list(indices)
+
+    def get_attr(self, attr_name, indices=None):
+        return [getattr(self.envs[i], attr_name) for i in self._indices(indices)]
 
     def set_attr(self, attr_name, value, indices=None):
         raise AttributeError(f"MeshVecEnv has no settable per-env attribute {attr_name!r}")
 
     def env_method(self, method_name, *args, indices=None, **kwargs):
-        raise AttributeError(f"MeshVecEnv has no per-env method {method_name!r}")
+        return [getattr(self.envs[i], method_name)(*args, **kwargs) for i in self._indices(indices)]
 
     def env_is_wrapped(self, wrapper_class, indices=None):
-        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
-        return [False for _ in idx]
+        return [False for _ in self._indices(indices)]
 
     def render(self, mode="human"):
+        return None
+
+
+class EnvView(EpisodeTools):
+    """Environment k of a MeshVecEnv as the reference's callers address one env: ``generated_meshes``, ``save_meshes``,
+    ``get_quality``, the exports (EpisodeTools) and the state fields of ``MeshVecEnv.get_state`` as attributes."""
+
+    render_mode = None          # what SB3 2.x's VecEnv.__init__ asks every env for
+
+    def __init__(self, vec: MeshVecEnv, k: int):
+        self._vec, self._k = vec, int(k)
+
+    @property
+    def points(self):
+        return self._vec.domains[int(self._vec.env_domain[self._k])]
+
+    @property
+    def observation_space(self):
+        return self._vec.observation_space
+
+    @property
+    def action_space(self):
+        return self._vec.action_space
+
+    def get_last_episode(self):
+        return self._vec.get_last_episode(self._k)
+
+    def __getattr__(self, name):            # n, ring_ids, ring_xy, ref_id, n_elem, status, ...
+        if name.startswith("_"):
+            raise AttributeError(name)
+        st = self._vec.get_state(self._k)
+        if name in st:
+            return st[name]
+        raise AttributeError(name)
+
+
+class _EnvViews:
+    """Lazy sequence of EnvView (a 65 536-env batch does not build 65 536 objects to serve ``envs[0]``)."""
+
+    def __init__(self, vec):
+        self._vec, self._made = vec, {}
+
+    def __len__(self):
+        return self._vec.num_envs
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        k = int(k)
+        if k < 0:
+            k += len(self)
+        if not 0 <= k < len(self):
+            raise IndexError(k)
+        if k not in self._made:
+            self._made[k] = EnvView(self._vec, k)
+        return self._made[k]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class SB3MeshVecEnv(MeshVecEnv, VEC_ENV_BASE):
+    """The vectorised drop-in for Stable-Baselines3: a ``stable_baselines3.common.vec_env.VecEnv`` subclass (when SB3 is
+    importable; a plain class with the same methods otherwise) over the HIP engine, replacing ``DummyVecEnv([lambda: env])``
+    of rl/baselines/dummy_vec_env.py:12-125 -- ``SAC('MlpPolicy', SB3MeshVecEnv([boundary(0)], n_envs=4096), ...)``.
+
+    ``reset()`` -> obs float32 [n, 18] (numpy); ``step_async(actions)`` / ``step_wait()`` / ``step(actions)`` ->
+    (obs, float32 rewards, bool dones, infos) with auto-reset, ``infos[k]["terminal_observation"]`` and
+    ``infos[k]["TimeLimit.truncated"]`` on the envs that finished; ``envs[k]`` / ``get_attr`` / ``env_method`` reach the
+    per-env tools (``generated_meshes``, ``save_meshes``, ...).  The tensor-native calls stay available as
+    ``reset_tensor()`` / ``step_tensor()``.  auto_reset=False gives the reference's own DummyVecEnv variant, whose reset is
+    commented out (rl/baselines/dummy_vec_env.py:49) for the evaluation callback."""
+
+    def __init__(self, *args, **kwargs):
+        kwargs.setdefault("lazy_infos", False)      # SB3's Monitor-less paths write into infos[k]: one dict per env
+        MeshVecEnv.__init__(self, *args, **kwargs)
+
+    def _finish_init(self):
+        MeshVecEnv._finish_init(self)
+        if VEC_ENV_BASE is not object:
+            n = self.num_envs            # VecEnv.__init__ assigns num_envs / observation_space / action_space (+ SB3 2.x bookkeeping)
+            VEC_ENV_BASE.__init__(self, n, self.observation_space, self.action_space)
+        if not hasattr(self, "reset_infos"):
+            self.reset_infos = [{} for _ in range(self.num_envs)]
+
+    def reset(self):
+        obs = self.reset_numpy()
+        self.reset_infos = [{} for _ in range(self.num_envs)]
+        if hasattr(self, "_reset_seeds"):
+            self._reset_seeds()
+        if hasattr(self, "_reset_options"):
+            self._reset_options()
+        return obs
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        MeshVecEnv.close(self)
+
+    def get_images(self):
+        return [None for _ in range(self.num_envs)]
+
+    def render(self, mode=None):
         return None

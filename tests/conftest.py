@@ -17,7 +17,7 @@ def pytest_configure(config):
 def golden_names():
     """Recorded reference traces (quality_*.npz holds element records, not a trace)."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
-                  if f.endswith(".npz") and not f.startswith(("quality_", "move_", "smooth", "samples_", "front_")))
+                  if f.endswith(".npz") and not f.startswith(("quality_", "move_", "smooth", "samples_", "front_", "plot_")))
 
 
 def move_golden_names():

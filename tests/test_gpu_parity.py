@@ -101,8 +101,9 @@ def test_cu_group_kernel_matches_reference_trace(torch_cuda, name, n_envs):
     if len(pts) <= 64:
         assert f"k_step_group<{16 if n_envs == 4096 else 8}" in env.step_kernel, env.step_kernel
     elif "k_step_group" not in env.step_kernel:     # sixteen 224-slot rings exceed one CU's LDS: one wave per workgroup
+        kernel = env.step_kernel
         env.close()
-        pytest.skip(f"{name} at {n_envs} envs runs on {env.step_kernel}")
+        pytest.skip(f"{name} at {n_envs} envs runs on {kernel}")
     obs = env.reset().cpu().numpy()
     assert (obs == tr["reset_obs"][None]).all()
     probe = [0, 1, 15, 16, n_envs // 2 + 3, n_envs - 1]
