@@ -1731,3 +1731,21 @@ void meshenv_ref_step_batch(RefEnv **envs, int n, const float *actions, float *o
         }
     }
 }
+
+/* T vector steps in ONE parallel region (the CPU baseline's best form: no fork / join per vector step, every env's state
+ * stays in its thread's cache): thread-private env ranges, actions [T][n][3]; outputs of the LAST step only (obs / reward /
+ * flags as meshenv_ref_step_batch writes them). */
+void meshenv_ref_rollout_batch(RefEnv **envs, int n, int T, const float *actions, float *obs, double *reward,
+                               uint8_t *done, uint8_t *is_complete, int auto_reset, int threads)
+{
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int i = 0; i < n; i++) {
+        for (int t = 0; t < T; t++) {
+            meshenv_ref_step(envs[i], actions + ((size_t)t * n + i) * 3, obs + 18 * i, reward + i, done + i, is_complete + i);
+            if (done[i] && auto_reset) meshenv_ref_reset(envs[i], obs + 18 * i);
+        }
+    }
+}

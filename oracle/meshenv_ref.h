@@ -94,6 +94,9 @@ void meshenv_ref_quality_stats(const double *vals /*[n][8]*/, int n, double *sta
 void meshenv_ref_step_batch(RefEnv **envs, int n, const float *actions, float *obs, double *reward,
                             uint8_t *done, uint8_t *is_complete, float *terminal_obs, int auto_reset,
                             int threads);
+/* T vector steps in one OpenMP parallel region (cpu_baseline leg of bench.py); outputs of the last step */
+void meshenv_ref_rollout_batch(RefEnv **envs, int n, int T, const float *actions /*[T][n][3]*/, float *obs, double *reward,
+                               uint8_t *done, uint8_t *is_complete, int auto_reset, int threads);
 
 /* libm calls made by the CALLING thread since the last reset: out[3] = atan2, sin, cos (bench.py reports the
  * reference algorithm's fp64 transcendental count per env-step; meaningful for threads == 1 runs) */

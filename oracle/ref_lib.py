@@ -246,3 +246,12 @@ class RefBatch:
         self.L.meshenv_ref_step_batch(self.handles, self.n, a, self.obs, self.reward, self.done, self.complete,
                                       self.terminal_obs.ctypes.data_as(C.c_void_p), int(auto_reset), int(threads))
         return self.obs, self.reward, self.done, self.complete
+
+    def rollout(self, actions, auto_reset=True, threads=1):
+        """T vector steps (actions [T, n, 3]) in one OpenMP parallel region; returns the outputs of the last step."""
+        a = np.ascontiguousarray(actions, np.float32).reshape(-1, self.n, 3)
+        self.L.meshenv_ref_rollout_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, _f32p, _f32p, _f64p, _u8p, _u8p, C.c_int, C.c_int]
+        self.L.meshenv_ref_rollout_batch.restype = None
+        self.L.meshenv_ref_rollout_batch(self.handles, self.n, int(a.shape[0]), a, self.obs, self.reward, self.done,
+                                         self.complete, int(auto_reset), int(threads))
+        return self.obs, self.reward, self.done, self.complete

@@ -66,9 +66,7 @@ struct GroupActorArgsT {
     unsigned long long *dbg; // nullable: [grid][T][4] s_memrealtime stamps per workgroup and step (tools/tsteps_timeline.py)
 };
 
-#ifndef MESHENV_T_ALL3
-#define MESHENV_T_ALL3 true    // (false: 117 spilled VGPRs instead of 77; the hardware thread id for the actor: 147 -- its weight loads are hoisted)
-#endif
+// (all three weight layers requested up front: requesting only the first spills 117 VGPRs instead of 77)
 template <bool kDefaultParams>
 __global__ void __launch_bounds__(64 * 16)
 k_step_group_actor_T(GroupActorArgsT A)
@@ -102,7 +100,7 @@ k_step_group_actor_T(GroupActorArgsT A)
         const aptr Bp = (aptr)ka;
         const ActorWeights W = Bp->W;
         ActorHead hd;
-        actor_request_weights(hd, W, tid, MESHENV_T_ALL3);
+        actor_request_weights(hd, W, tid, true);
         if (dbg && tid == 0) dbg[((size_t)blockIdx.x * T + tt) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
         __syncthreads();
         if (dbg && tid == 0) dbg[((size_t)blockIdx.x * T + tt) * 4 + 2] = __builtin_amdgcn_s_memrealtime();

@@ -151,7 +151,8 @@ struct MeshEnv {
     bool front_moved = false;          // a front smoother ran since the last full reset: rings may hold off-lattice vertices
     bool smooth_final_ready = false;
     bool fused_ready = false;          // k_step_group_actor's LDS attribute set
-    bool fused_T_ready = false;        // k_step_group_actor_T's
+    bool fused_T_ready = false;        // k_step_group_actor_T's (-DMESHENV_DEV build only)
+    int stage_bits = 0;                // bits 1 | 2 of k_step's auto_reset argument: record-first / key-less staging (set at creation)
     bool samples_ready = false;        // k_extract_samples' LDS attribute set
     // move() API state, allocated by the first meshenv_move: not_valid_points per env
     double2 *nv_xy = nullptr;    // [E][cap]
@@ -368,7 +369,13 @@ static int create_impl(int device, int n_domains, const int32_t *dom_offsets_hos
             while (g * 2 <= n_envs / n_cu && g * 2 <= 16) g *= 2;
             want = g >= 8 ? g : 1;
         }
+        // (G = 4, the speculative kernel and the T-step closed-loop kernel are measured-slower experiments: they exist in the
+        // -DMESHENV_DEV build that tools/ and tests/test_gpu_variants.py compile, not in the shipped library)
+#ifdef MESHENV_DEV
         for (int g : {16, 8, 4})
+#else
+        for (int g : {16, 8})
+#endif
             if (g <= want && group_lds_bytes(cap, g) <= 150 * 1024) { G = g; break; }
         if (!force && (G < 8 || n_envs > n_cu * G)) G = 1;  // LDS forced a smaller group: more than one workgroup per CU
         // Ragged packing: sixteen rings of the LONGEST stride do not fit, sixteen rings of their own lengths may (mixed
@@ -406,16 +413,39 @@ static int create_impl(int device, int n_domains, const int32_t *dom_offsets_hos
         // The speculative form of the CU-group kernel (k_step_spec: two ring buffers per env, no workgroup barrier) is
         // opt-in, MESHENV_SPEC=1: measured on MI355X at 4096 x boundary() it takes 16.7 us per launch against 15.5 us
         // for the barrier + deal form (rocprofv3; DESIGN.md section 5 says why), so the default stays k_step_group.
+#ifdef MESHENV_DEV
         const char *spec_env = getenv("MESHENV_SPEC");
         h->spec = h->env_lds_host.empty() && (G == 16 || G == 8) && spec_lds_bytes(cap, G) <= 150 * 1024 && spec_env && atoi(spec_env) == 1;
+#else
+        h->spec = false;
+#endif
+        // staging mode of the one-wave-per-env step kernel (bits 1, 2 of its auto_reset argument), decided once per handle:
+        // record-first staging (memoised rejections never load their ring) -- measured never slower from 8192 envs up,
+        // +9..15 % at 32 768+; the ring staged without candidate keys / stamps -- +0..3 % from 32 768 envs, -2 % at 8192.
+        // MESHENV_LAZY / MESHENV_LIGHT override the size rule (A/B switches, read here, not per launch).
+        {
+            const char *lz = getenv("MESHENV_LAZY");
+            const bool lazy = lz ? atoi(lz) != 0 : n_envs >= 8192;
+            const char *lt = getenv("MESHENV_LIGHT");
+            const bool light = lt ? atoi(lt) != 0 : (lazy && n_envs >= 16384);
+            h->stage_bits = (lazy ? 2 : 0) | (light ? 4 : 0);
+        }
+#ifdef MESHENV_DEV
         if (h->spec) {
             h->group_lds = spec_lds_bytes(cap, G);
             if (h->group_lds > 64 * 1024) {
                 const void *fn = G == 16 ? (const void *)k_step_spec<16, true> : (const void *)k_step_spec<8, true>;
                 CREATE_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
             }
-        } else if (G > 1 && h->group_lds > 64 * 1024) {
-            const void *fn = G == 16 ? (const void *)k_step_group<16, true> : G == 8 ? (const void *)k_step_group<8, true> : (const void *)k_step_group<4, true>;
+        } else
+#endif
+        if (G > 1 && h->group_lds > 64 * 1024) {
+            const bool ragged = !h->env_lds_host.empty();
+            const void *fn = ragged ? (const void *)k_step_group<16, true, true>
+                             : G == 16 ? (const void *)k_step_group<16, true> : (const void *)k_step_group<8, true>;
+#ifdef MESHENV_DEV
+            if (G == 4) fn = (const void *)k_step_group<4, true>;
+#endif
             CREATE_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         }
     }
@@ -1166,11 +1196,15 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         A.env_lds = h->env_lds;
         A.ho_off = h->ho_off;
         A.pad = 0;
+#ifdef MESHENV_DEV
         if (h->spec && G == 16) hipLaunchKernelGGL((k_step_spec<16, true>), grid, block, h->group_lds, h->stream, A);
         else if (h->spec && G == 8) hipLaunchKernelGGL((k_step_spec<8, true>), grid, block, h->group_lds, h->stream, A);
+        else if (G == 4) hipLaunchKernelGGL((k_step_group<4, true>), grid, block, h->group_lds, h->stream, A);
+        else
+#endif
+        if (h->env_lds) hipLaunchKernelGGL((k_step_group<16, true, true>), grid, block, h->group_lds, h->stream, A);   // ragged: G == 16 only
         else if (G == 16) hipLaunchKernelGGL((k_step_group<16, true>), grid, block, h->group_lds, h->stream, A);
-        else if (G == 8) hipLaunchKernelGGL((k_step_group<8, true>), grid, block, h->group_lds, h->stream, A);
-        else hipLaunchKernelGGL((k_step_group<4, true>), grid, block, h->group_lds, h->stream, A);
+        else hipLaunchKernelGGL((k_step_group<8, true>), grid, block, h->group_lds, h->stream, A);
     } else {
         const dim3 grid(h->n_envs), block(64);
 #define MESHENV_LAUNCH_STEP(MULTI, DEF)                                                                                      \
@@ -1183,12 +1217,8 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         else hipLaunchKernelGGL((k_step<MULTI, DEF>), grid, block, h->lds, h->stream, ka);                                   \
     } while (0)
         if (n_steps == 1) {
-            // bit 1: record-first staging (memoised rejections never load their ring), throughput regime only
-            const char *lz = getenv("MESHENV_LAZY");
-            const bool lazy = lz ? atoi(lz) != 0 : h->n_envs >= 8192;  // measured: never slower from 8192 envs up, +9..15 % at 32768+
-            const char *lt = getenv("MESHENV_LIGHT");   // bit 2: the ring staged without candidate keys / stamps (A/B switch)
-            const bool light = lt ? atoi(lt) != 0 : (lazy && h->n_envs >= 16384);  // measured: +0..3 % from 32 768 envs, -2 % at 8 192
-            auto_reset = (auto_reset ? 1 : 0) | (lazy ? 2 : 0) | (light ? 4 : 0);
+            // bit 1: record-first staging, bit 2: key-less staging -- throughput regime only, decided in meshenv_create
+            auto_reset = (auto_reset ? 1 : 0) | h->stage_bits;
             if (h->default_params) MESHENV_LAUNCH_STEP(false, true);
             else MESHENV_LAUNCH_STEP(false, false);
         } else {
@@ -1795,6 +1825,10 @@ int meshenv_extract_samples(MeshEnv *h, int which, const uint8_t *mask_dev, int 
     return MESHENV_OK;
 }
 
+#ifdef MESHENV_DEV
+static unsigned long long *g_tsteps_dbg = nullptr;
+#endif
+
 int meshenv_step_actor_multi(MeshEnv *h, MeshActor *a, int T, float *actions_dev, float *obs_dev, double *reward_dev, uint8_t *done_dev,
                          uint8_t *complete_dev, float *terminal_obs_dev, int auto_reset, int sample, uint64_t seed, uint64_t counter,
                          float *eps_out_dev)
@@ -1811,8 +1845,15 @@ int meshenv_step_actor_multi(MeshEnv *h, MeshActor *a, int T, float *actions_dev
         return MESHENV_E_STATE;
     }
     const size_t n = (size_t)h->n_envs;
+    // One launch for all T steps (k_step_group_actor_T) measured SLOWER than T fused single-step launches (DESIGN.md section 5,
+    // round 3: 95 spilled VGPRs, 384 B of scratch per lane): that kernel is compiled in the -DMESHENV_DEV build only, where
+    // tools/tsteps_timeline.py and tests/test_gpu_variants.py drive it; the shipped library always takes the step-by-step form.
+#ifdef MESHENV_DEV
     const bool fusable = h->group == 16 && !h->spec && h->default_params && !h->front_moved && !h->env_lds && h->timing == 0 && !h->reselect_pending &&
                          group_actor_lds_bytes(h->cap) <= 160 * 1024 && !h->S.msg;
+#else
+    const bool fusable = false;
+#endif
     if (!fusable || T == 1) {   // the same results step by step
         for (int t = 0; t < T; t++) {
             const int rc = meshenv_step_actor(h, a, actions_dev + (size_t)t * n * 3, obs_dev + (size_t)t * n * kObsDim, reward_dev + (size_t)t * n,
@@ -1824,6 +1865,7 @@ int meshenv_step_actor_multi(MeshEnv *h, MeshActor *a, int T, float *actions_dev
         }
         return MESHENV_OK;
     }
+#ifdef MESHENV_DEV
     MESHENV_ON_DEVICE(h);
     if (!h->fused_T_ready) {
         HIP_TRY(h, hipFuncSetAttribute((const void *)k_step_group_actor_T<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1844,11 +1886,22 @@ int meshenv_step_actor_multi(MeshEnv *h, MeshActor *a, int T, float *actions_dev
     GA.sample = sample ? 1 : 0;
     GA.T = T;
     GA.dbg = nullptr;
-    if (const char *dp = std::getenv("MESHENV_TSTEPS_DBG")) GA.dbg = (unsigned long long *)std::strtoull(dp, nullptr, 0);   // dev tool only
+    GA.dbg = g_tsteps_dbg;   // nullptr unless tools/tsteps_timeline.py set a stamp buffer (meshenv_dev_set_tsteps_dbg)
     hipLaunchKernelGGL((k_step_group_actor_T<true>), dim3((h->n_envs + 15) / 16), dim3(64 * 16), group_actor_lds_bytes(h->cap), h->stream, GA);
     HIP_TRY(h, hipGetLastError());
     h->steps_done += (uint64_t)T;
+#endif
     return MESHENV_OK;
 }
+
+#ifdef MESHENV_DEV
+// Dev build only (tools/tsteps_timeline.py): a device buffer of at least grid * T * 4 u64 words that the next
+// meshenv_step_actor_multi launches stamp; nullptr switches the stamps off.  Not part of include/meshenv.h.
+int meshenv_dev_set_tsteps_dbg(unsigned long long *buf_dev)
+{
+    g_tsteps_dbg = buf_dev;
+    return MESHENV_OK;
+}
+#endif
 
 }  // extern "C"

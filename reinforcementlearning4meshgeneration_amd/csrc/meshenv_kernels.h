@@ -124,13 +124,9 @@ __device__ __forceinline__ int spin_until_nonzero(volatile int *w)
 // two selects.
 __device__ __forceinline__ int wrapi(int i, int n)
 {
-#ifdef MESHENV_WRAPI_SELECT
-    return i < 0 ? i + n : (i >= n ? i - n : i);
-#else
     const unsigned a = (unsigned)i, b = (unsigned)(i + n), c = (unsigned)(i - n);
     const unsigned m = a < b ? a : b;
     return (int)(m < c ? m : c);
-#endif
 }
 
 __host__ __device__ __forceinline__ size_t lds_bytes_for(int cap)
@@ -619,10 +615,6 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     // ---- reductions: first-wins minima as packed (value bits, order) keys, one interleaved DPP scan
     u64 rk = (u64)__double_as_longlong(rbest), mk = (u64)__double_as_longlong(m_d);
     const u64 my_rk = rk;
-#ifdef MESHENV_DPP_REDUCTIONS
-    wave_min5_u64(k0, k1, k2, rk, mk);
-    const unsigned ro = wave_min_u32(my_rk == rk ? (unsigned)rord : 0xffffffffu);  // earliest among equal hits
-#else
     // Only the few lanes whose vertex lies inside the fan (or whose edge the bisector hits) hold anything but the identity:
     // they take the minima with LDS atomics -- five DPP reductions of 64-bit keys are ~170 instructions on the one
     // wavefront whose issue slot the whole extraction runs on, this is ~40 and three LDS round trips.
@@ -640,7 +632,6 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     if (my_rk == rk && rk != rk_init) atomicMin(&red[5], (u64)(unsigned)rord);   // earliest among equal hits
     wave_sync();
     const unsigned ro = (unsigned)red[5];
-#endif
     rbest = __longlong_as_double((long long)rk);
     m_d = __longlong_as_double((long long)mk);
     const float s0 = __uint_as_float((unsigned)(k0 >> 32)), s1 = __uint_as_float((unsigned)(k1 >> 32)), s2 = __uint_as_float((unsigned)(k2 >> 32));
@@ -745,7 +736,7 @@ __device__ __forceinline__ bool point_inside(Ctx &c, const Params &prm, P2 p)
     const int n = c.n;
     const P2 far = mkp(prm.ray_length, p.y);
     int parity = 0;
-#if !defined(MESHENV_NO_FILTERS) && !defined(MESHENV_NO_PIP_FILTER)
+#ifndef MESHENV_NO_FILTERS
     if (n > 64) {
         // Rings of several 64-vertex chunks: an exact pre-filter per edge, the survivors compacted (c.list), and the
         // crossing test itself once over the survivors instead of once per chunk.  An edge whose endpoints lie strictly on
@@ -754,7 +745,7 @@ __device__ __forceinline__ bool point_inside(Ctx &c, const Params &prm, P2 p)
         // straddle(p, far, vi, vm) fail sin_rounds_to_zero's first test (|c| > 1e-3 |d|: c = -a (L - p.x), d = dx (L - p.x))
         // and its cross products -(L - p.x) a and -(L - p.x) b have the same sign and cannot underflow: straddle is False,
         // is_cross is False, the edge adds nothing.  Identical results by construction (the filter only drops edges the full
-        // test rejects); -DMESHENV_NO_FILTERS / -DMESHENV_NO_PIP_FILTER build the unfiltered form.
+        // test rejects); -DMESHENV_NO_FILTERS builds the unfiltered form.
         int count = 0;
         for (int i0 = 0; i0 < n; i0 += 64) {
             const int i = i0 + c.lane;
@@ -1247,7 +1238,6 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
         f.ref = p0;
         f.mp0 = -1; f.mp1 = wrapi(index - 1, n); f.mp2 = index; f.mp3 = wrapi(index + 1, n);
         bool same;
-#ifndef MESHENV_NO_FUSED_PIP
         if (fuse_passes && n <= 64) {
             // One ring pass for the three per-vertex tests of a rule-0 point -- crossing parity (M:539-546), find_same_point
             // and the distance filter of the quad [new, i-1, i, i+1]: their dependency chains are independent, so the
@@ -1270,7 +1260,6 @@ __device__ __forceinline__ Decision env_check(Ctx &c, const DevState &S, float a
                 return d;
             }
         } else
-#endif
         {
             const bool inside = point_inside(c, prm, new_point);
             MESHENV_STAMP(c, 2);
@@ -1841,13 +1830,9 @@ k_step(const KStepArgs A)
 #ifndef MESHENV_STAMPS
     // (requested with the rest of the state in the T-step instantiation: no round trip at the end; the one-step
     // instantiation reads them in its epilogue, when the step changed the ring)
-#if defined(MESHENV_EARLY_COUNTERS) || defined(MESHENV_NO_LATE_ARGS)
-    const EnvCounters cnt0 = S.cnt[env];
-#else
     EnvCounters cnt0;
     cnt0.last_change = 0; cnt0.valid = 0; cnt0.sum_n = 0; cnt0.sum_n_valid = 0;
     if (kMulti) cnt0 = S.cnt[env];
-#endif
 #endif
     if (light) load_env(c, S, env, false);
     else load_env(c, S, env);
@@ -1883,14 +1868,12 @@ k_step(const KStepArgs A)
             env_apply(c, S, d);
         }
         const StepResult r = env_finish(c, S.prm, d);
-#if !defined(MESHENV_STAMPS) && !defined(MESHENV_NO_LATE_ARGS)
+#ifndef MESHENV_STAMPS
         if (!kMulti) {   // one step per launch: the epilogue on freshly read arguments (see late_kstep_args)
             const KStepArgs L = late_kstep_args<kDefaultParams>();
             const bool l_auto = (L.auto_reset & 1) != 0;   // (bits 1, 2 of the argument select the staging mode)
             if (r.valid || (r.done && l_auto)) {
-#ifndef MESHENV_EARLY_COUNTERS
                 k = L.S.cnt[env];   // (the work counters too: one step in nine needs them, and only here)
-#endif
                 const unsigned long long next = L.step0 + 1ULL;
                 k.sum_n += (unsigned long long)n_before * (next - k.last_change);
                 k.last_change = next;
@@ -1935,7 +1918,7 @@ k_step(const KStepArgs A)
         }
         last_reward = r.reward; last_done = r.done; last_complete = r.complete;
         if (r.done) {
-#if !defined(MESHENV_STAMPS) && !defined(MESHENV_NO_LATE_ARGS)
+#ifndef MESHENV_STAMPS
             // (T steps per launch: the end of an episode -- one step in ~25 -- reads what it needs afresh; the per-step
             // stores keep their pointers: re-reading those on every step of one wave's serial chain cost 11 %)
             const KStepArgs L = late_kstep_args<kDefaultParams>();
@@ -1947,7 +1930,7 @@ k_step(const KStepArgs A)
 #endif
         }
     }
-#if !defined(MESHENV_STAMPS) && !defined(MESHENV_NO_LATE_ARGS)
+#ifndef MESHENV_STAMPS
     {   // the epilogue of the T-step launch on freshly read arguments (the one-step instantiation has returned above)
         const KStepArgs L = late_kstep_args<kDefaultParams>();
         if (c.lane < kObsDim) L.obs_out[(size_t)env * kObsDim + c.lane] = c.obs;
@@ -2142,9 +2125,6 @@ __device__ __forceinline__ StepOuts late_outs(const int tstep = 0, const int n_e
 // holding them costs scalar registers (or VGPR lanes) on every path.  prm comes from the caller's copy (literals).
 __device__ __forceinline__ DevState late_state(const DevState &S, KernArgPtr ka_in = nullptr)
 {
-#ifdef MESHENV_NO_LATE_ARGS
-    return S;
-#else
     typedef const __attribute__((address_space(4))) unsigned long long *qptr;
     qptr q = (qptr)(ka_in ? ka_in : (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr());
     asm volatile("" : "+s"(q));   // not before this point
@@ -2155,7 +2135,6 @@ __device__ __forceinline__ DevState late_state(const DevState &S, KernArgPtr ka_
 #pragma unroll
     for (unsigned i = 0; i < kWords; i++) u.w[i] = q[i];
     return u.s;
-#endif
 }
 
 // reward / flags / observation of one finished step, auto-reset, state write-back, work counters
@@ -2222,7 +2201,9 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S_in, c
 // ~40 scalars are handed over (Handoff).  Environments stay independent: no data is shared between envs.
 // (the body as a function: k_step_group is just this; k_step_group_actor, csrc/meshenv_fused.h, appends the policy's forward)
 // (actor_in: k_step_group_actor only -- LDS [G][132] floats, the actor's first-layer input; nullptr otherwise)
-template <int G, bool kDefaultParams>
+// (kRagged: the workgroup's LDS is packed by each env's own ring length, GroupArgs::env_lds -- batches of mixed domains only;
+// the uniform instantiation holds no offset table, no per-env region lookup and no Handoff fields for them)
+template <int G, bool kDefaultParams, bool kRagged = false>
 __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor_in = nullptr, const int tstep = 0,
                                                 KernArgPtr ka = nullptr, const int tid_in = -1)
 {
@@ -2235,8 +2216,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     if (kDefaultParams) apply_default_params(S.prm);
     const int wave = uniform_i32(tid >> 6);  // wave-uniform by construction: keeps env and every address derived from it in SGPRs
     const size_t env_bytes = lds_bytes_for(cap);
-    const int2 *env_lds = A.env_lds;   // ragged packing (nullptr: uniform regions of env_bytes)
-    Handoff *ho = (Handoff *)((char *)smem + (env_lds ? (size_t)A.ho_off : (size_t)G * env_bytes));
+    Handoff *ho = (Handoff *)((char *)smem + (kRagged ? (size_t)A.ho_off : (size_t)G * env_bytes));
     const int env = blockIdx.x * G + wave;
     const bool active = env < S.n_envs;
     SPEC_TIME(env, 8);
@@ -2249,23 +2229,18 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     if (active) {
         Ctx c;
         int my_off = (int)((size_t)wave * env_bytes), my_cap = cap;
-        if (env_lds) {   // wave-uniform: one scalar load, requested with the state
-            const int2 e = env_lds[env];
+        if (kRagged) {   // wave-uniform: one scalar load, requested with the state
+            const int2 e = A.env_lds[env];
             my_off = uniform_i32(e.x);
             my_cap = uniform_i32(e.y);
         }
         carve_lds(c, (char *)smem + my_off, my_cap);
         const float *a = actions + (size_t)env * 3;
         const float a0 = a[0], a1 = a[1], a2 = a[2];
-#ifdef MESHENV_EARLY_COUNTERS
-        const EnvCounters cnt0 = S.cnt[env];
-        constexpr bool kCntLate = false;
-#else
         EnvCounters cnt0;
         cnt0.last_change = 0; cnt0.valid = 0; cnt0.sum_n = 0; cnt0.sum_n_valid = 0;
         constexpr bool kCntLate = true;
-#endif
-        load_env(c, S, env, true, tid_in >= 0 ? (tid & 63) : -1, env_lds ? my_cap : 0);
+        load_env(c, S, env, true, tid_in >= 0 ? (tid & 63) : -1, kRagged ? my_cap : 0);
         const int n_before = c.n;
         Decision d = env_check(c, S, a0, a1, a2, false, false, 0.0, 0.0, 0.5, nullptr, true);
         if (!d.ok) {
@@ -2276,11 +2251,8 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
                 Handoff &h = ho[wave];
                 h.env = env; h.n = c.n; h.ref = c.ref; h.n_elem = c.n_elem; h.failed = c.failed; h.n_new = c.n_new;
                 h.counter = c.counter; h.status = c.status; h.dom = c.dom;
-                h.lds_off = my_off; h.lds_cap = my_cap;
+                if (kRagged) { h.lds_off = my_off; h.lds_cap = my_cap; }
                 h.bl = c.bl; h.area = c.area; h.ct = c.ct; h.st = c.st;
-#ifdef MESHENV_EARLY_COUNTERS
-                h.cnt0 = cnt0;
-#endif
                 h.d = d;
                 h.upd_done = 0;
                 h.helper_done = 0;
@@ -2303,7 +2275,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
 #ifdef MESHENV_DBG_P1SET   // two of the check's stage stamps per build (tools/phase1_stages.py): 0 = decode, ring pass; 1 = quad, intersections
         {
             Ctx cs;
-            carve_lds(cs, (char *)smem + (env_lds ? env_lds[env].x : (int)((size_t)wave * env_bytes)), env_lds ? env_lds[env].y : cap);
+            carve_lds(cs, (char *)smem + (kRagged ? A.env_lds[env].x : (int)((size_t)wave * env_bytes)), kRagged ? A.env_lds[env].y : cap);
             o[4] = cs.sc->stamps[MESHENV_DBG_P1SET ? 4 : 1];
             o[5] = cs.sc->stamps[MESHENV_DBG_P1SET ? 5 : 2];
         }
@@ -2334,10 +2306,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
 #ifdef MESHENV_NO_HELPER
     const bool helpers = false;
 #else
-#ifndef MESHENV_HELPER_MAX_M
-#define MESHENV_HELPER_MAX_M 8
-#endif
-    const bool helpers = balanced && G >= 4 && 2 * m <= G && m <= MESHENV_HELPER_MAX_M;
+    const bool helpers = balanced && G >= 4 && 2 * m <= G && m <= 8;
 #endif
     if (balanced && G >= 4) {
         const int r = __popc(mine & ((1u << wave) - 1u));  // my rank among the waves of my SIMD
@@ -2374,7 +2343,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
         // ---- phase 2, helper: the reward of env ho[hsrc]
         Ctx c;
         Handoff &h = ho[hsrc];
-        if (env_lds) carve_lds(c, (char *)smem + uniform_i32(h.lds_off), uniform_i32(h.lds_cap));
+        if (kRagged) carve_lds(c, (char *)smem + uniform_i32(h.lds_off), uniform_i32(h.lds_cap));
         else carve_lds(c, (char *)smem + (size_t)hsrc * env_bytes, cap);
         c.lane = tid & 63;
         Decision d = h.d;
@@ -2400,7 +2369,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     // ---- phase 2: the update of env ho[src], in place in its LDS region
     Ctx c;
     Handoff &h = ho[src];
-    if (env_lds) carve_lds(c, (char *)smem + uniform_i32(h.lds_off), uniform_i32(h.lds_cap));
+    if (kRagged) carve_lds(c, (char *)smem + uniform_i32(h.lds_off), uniform_i32(h.lds_cap));
     else carve_lds(c, (char *)smem + (size_t)src * env_bytes, cap);
     c.lane = tid & 63;
     c.env = uniform_i32(h.env);
@@ -2416,11 +2385,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     d.p0 = uniform_i32(d.p0); d.p1 = uniform_i32(d.p1); d.p2 = uniform_i32(d.p2); d.p3 = uniform_i32(d.p3);
     d.t0 = uniform_i32(d.t0); d.t1 = uniform_i32(d.t1); d.lo = uniform_i32(d.lo); d.hi = uniform_i32(d.hi);
     d.ok = 1;
-#ifdef MESHENV_EARLY_COUNTERS
-    const EnvCounters cnt0 = h.cnt0;
-#else
     const EnvCounters cnt0 = S.cnt[c.env];   // requested now, used after the update: the round trip hides behind it
-#endif
     const int n_before = c.n;
     env_apply(c, S, d, helpers ? &h.upd_done : nullptr);
 #ifdef MESHENV_STAMPS
@@ -2444,11 +2409,11 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
 }
 
 
-template <int G, bool kDefaultParams>
+template <int G, bool kDefaultParams, bool kRagged = false>
 __global__ void __launch_bounds__(64 * G)
 k_step_group(GroupArgs A)
 {
-    step_group_body<G, kDefaultParams>(A);
+    step_group_body<G, kDefaultParams, kRagged>(A);
 }
 
 // ------------------------------------------------------------------------------------------ speculative CU-group kernel

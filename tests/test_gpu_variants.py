@@ -2,6 +2,9 @@
   -DMESHENV_NO_HELPER   CU-group kernel with the reward on the update wave (no helper wavefront, no inter-wave LDS flags)
   -DMESHENV_NO_FILTERS  kernels without the exactness-preserving shortcuts (reference evaluation everywhere: the exact
                         atan2 instead of cw_fast, no collinearity shortcut, ...)
+  -DMESHENV_DEV         the measured-slower experiments the shipped library no longer instantiates: the speculative CU-group
+                        kernel (k_step_spec, MESHENV_SPEC=1), the T-steps-per-launch closed loop (k_step_group_actor_T) and
+                        k_step_group<4> -- their own tests (test_gpu_parity.py, test_gpu_actor.py) re-run against that build
 Each variant is compiled here with hipcc (the GPU box has the same image) and run in a process of its own (MESHENV_LIB
 selects the library at load time) through a short lockstep with the oracle; the default library's outputs on the same
 actions must be identical to the variants' bit for bit."""
@@ -61,3 +64,15 @@ def test_no_helper_and_no_filters_builds_agree_with_the_default_library():
         res = _run(_build(name, flags))
         assert res["valid"] == base["valid"] and res["obs_mismatch"] == 0, (name, res)
         assert res["checksum"] == base["checksum"], (name, res["checksum"], base["checksum"])
+
+
+def test_dev_build_runs_the_experimental_kernels():
+    """The kernels behind -DMESHENV_DEV keep their parity tests: the speculative kernel against the oracle and the default
+    kernel, the T-step closed loop against T single-step launches (bit-identical histories)."""
+    lib = _build("dev", ["-DMESHENV_DEV"])
+    env = dict(os.environ, MESHENV_LIB=lib)
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py") + "::test_speculative_group_kernel_variant",
+                        os.path.join(ROOT, "tests", "test_gpu_actor.py") + "::test_t_steps_per_launch_equals_single_step_launches"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0 and "2 passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]

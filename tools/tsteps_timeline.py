@@ -19,10 +19,14 @@ nxt = actor.sample(env.obs, seed=1, counter=0).clone()
 for k in range(6):
     h = env.step_actor_T(actor, nxt, T, seed=1, counter=1 + k * T); nxt = h["actions"][T].clone()
 dbg = torch.zeros((n // 16, T, 4), dtype=torch.int64, device="cuda")
-os.environ["MESHENV_TSTEPS_DBG"] = str(dbg.data_ptr())
+import ctypes
+from reinforcementlearning4meshgeneration_amd import _capi
+L = _capi.load()     # MESHENV_LIB must point at a -DMESHENV_DEV build (tools/build_variant.sh dev -DMESHENV_DEV)
+L.meshenv_dev_set_tsteps_dbg.argtypes = [ctypes.c_void_p]
+L.meshenv_dev_set_tsteps_dbg(dbg.data_ptr())
 h = env.step_actor_T(actor, nxt, T, seed=1, counter=1000)
 torch.cuda.synchronize()
-del os.environ["MESHENV_TSTEPS_DBG"]
+L.meshenv_dev_set_tsteps_dbg(None)
 d = dbg.cpu().numpy().astype(np.float64) * 0.01   # us
 valid_per_wg = None
 body = d[:, :, 1] - d[:, :, 0]; wait = d[:, :, 2] - d[:, :, 1]; act = d[:, :, 3] - d[:, :, 2]; step = d[:, :, 3] - d[:, :, 0]
