@@ -100,6 +100,23 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
+def cpu_quota():
+    """CPUs this process may use: (cores, source) -- the cgroup CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us,
+    rounded up) capped by the affinity mask; None when no quota is set."""
+    def read(path):
+        try:
+            return open(path).read().split()
+        except OSError:
+            return None
+    v2 = read("/sys/fs/cgroup/cpu.max")
+    if v2 and len(v2) == 2 and v2[0] != "max":
+        return -(-int(v2[0]) // int(v2[1])), "/sys/fs/cgroup/cpu.max = " + " ".join(v2)
+    q, per = read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+    if q and per and int(q[0]) > 0:
+        return -(-int(q[0]) // int(per[0])), f"cpu.cfs_quota_us / cpu.cfs_period_us = {q[0]} / {per[0]}"
+    return None, ("/sys/fs/cgroup/cpu.max = " + " ".join(v2)) if v2 else "no cgroup CPU controller visible"
+
+
 def cpu_baseline(n_envs, seed, doms, env_domain, wl, budget_s=12.0):
     """The CPU oracle (oracle/meshenv_ref.c, plain C, host libm) on the same workload, bounded sample."""
     from oracle.ref_lib import RefBatch, RefEnv, math_calls
@@ -125,24 +142,42 @@ def cpu_baseline(n_envs, seed, doms, env_domain, wl, budget_s=12.0):
     n_atan2, n_sin, n_cos = math_calls(reset=True)
     one = n_envs * T1 / dt1
     affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # "all cores": 16 threads = the CPU share of a one-GPU box of the pool, and -- where the affinity mask allows more -- up
-    # to 64 as well (a cgroup quota of 16 cores makes that run no faster: both are measured, the better one is reported)
+    # "all cores" = what this process may really use: min(cgroup CPU quota, affinity mask).  Without a quota the affinity
+    # mask alone can overstate it (a one-GPU box of the pool shows 256 CPUs and gives 16), so 16 threads -- the pool's CPU
+    # share per GPU -- are measured next to the full mask and the better run is reported.  The all-cores leg runs T vector
+    # steps inside ONE OpenMP parallel region (meshenv_ref_rollout_batch: dynamic schedule over envs, chunks of 8 envs, each
+    # thread stepping its envs T times) -- no fork / join per vector step, the CPU's best form of this workload.
+    quota, quota_src = cpu_quota()
     want = int(os.environ.get("MESHENV_CPU_THREADS", "0"))
-    tries = [want] if want > 0 else sorted({max(1, min(affinity, 16)), max(1, min(affinity, 64))})
+    if want > 0:
+        tries = [want]
+    elif quota is not None:
+        tries = [max(1, min(quota, affinity))]
+    else:
+        tries = sorted({max(1, min(affinity, 16)), affinity})
+
+    def run_region(T, threads):
+        acts = rng.uniform(lo, hi, size=(T, n_envs, 3)).astype(np.float32)
+        t0 = time.perf_counter()
+        batch.rollout(acts, auto_reset=True, threads=threads)
+        return time.perf_counter() - t0
+
     runs = []
     for cores in tries:
-        dtc = run(2, cores)
-        Tn = max(8, min(4000, int(0.5 * budget_s / len(tries) / (dtc / 2))))
-        dtn = run(Tn, cores)
+        dtc = run_region(4, cores)
+        Tn = max(16, min(8000, int(0.5 * budget_s / len(tries) / (dtc / 4))))
+        dtn = run_region(Tn, cores)
         runs.append(dict(value=n_envs * Tn / dtn, cores=cores, steps=Tn))
     best = max(runs, key=lambda r: r["value"])
     allc, cores, Tn = best["value"], best["cores"], best["steps"]
     per = float(n_envs * T1)
     return dict(value=one, unit="env-steps/s", cores=1, kind="port", cpu_model=cpu_model(),
                 sample=f"{n_envs} envs on {wl} x {T1} uniform-random vector steps, oracle/meshenv_ref.c, 1 thread",
-                all_cores=dict(value=allc, cores=cores, sched_getaffinity=affinity, cpu_count=os.cpu_count(), thread_counts_tried=runs,
+                all_cores=dict(value=allc, cores=cores, cgroup_cpu_quota=quota, cgroup_source=quota_src,
+                               sched_getaffinity=affinity, cpu_count=os.cpu_count(), thread_counts_tried=runs,
+                               openmp_schedule="one parallel region over the T steps of the sample; schedule(dynamic, 8) over envs",
                                sample=f"{n_envs} envs x {Tn} steps, OpenMP over envs, {cores} threads "
-                                      f"(sched_getaffinity allows {affinity}, the machine has {os.cpu_count()})"),
+                                      f"(cgroup quota {quota}, sched_getaffinity allows {affinity}, the machine has {os.cpu_count()})"),
                 fp64_transcendentals_per_env_step=dict(
                     atan2=n_atan2 / per, sin=n_sin / per, cos=n_cos / per,
                     note="libm calls of the reference algorithm (the oracle restates it call for call) on this sample; "
@@ -183,7 +218,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU (weak scaling: every rank owns this many)")
+    ap.add_argument("--envs-total", type=int, default=0,
+                    help="strong scaling: this many environments in all, split evenly over the ranks (4096 -> 4096 / N per GPU); "
+                         "overrides --envs, and the line says \"scaling\": \"strong\"")
+    ap.add_argument("--log-capacity", type=int, default=0,
+                    help="elements / created vertices logged per env and episode (generated_meshes, rl/boundary_env.py:192; "
+                         "boundary.vertices, general/mesh.py:589-590).  0 = the env keeps counts only (the headline)")
     ap.add_argument("--workload", default="boundary0", choices=["boundary0", "d1", "mixed", "random"],
                     help="boundary0 = the headline config (BASELINE.json configs[1]); d1 = boundary16 (120-vertex ring, "
                          "configs[2] domain); mixed = d1/d2/d3 interleaved (configs[3] shape); random = one "
@@ -230,6 +271,11 @@ def main():
     torch.cuda.set_device(dev)
 
     n, K, W = args.envs, args.steps, args.warmup
+    strong = args.envs_total > 0
+    if strong:
+        if args.envs_total % world:
+            raise SystemExit(f"--envs-total {args.envs_total} is not a multiple of the {world} ranks")
+        n = args.envs_total // world
     def golden_domain(name):
         tr = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
         return [tuple(p) for p in tr["domain_xy"]]
@@ -245,9 +291,9 @@ def main():
         doms = None   # generated on the device (meshenv_create_random); fetched back only for the CPU baseline leg
         env_domain, wl, wl_short = np.arange(n, dtype=np.int32), "one GenerateRandomPolygon ring per env (ui/GenerateRandomPolygon.py:5-49 from random.Random(seed + k), clockwise, densified to 0.45, generated on the device)", "GenerateRandomPolygon"
     if doms is None:
-        env = MeshVecEnv.from_random(n, 1000 + rank * n, device=local_rank, auto_reset=True, log_capacity=0)
+        env = MeshVecEnv.from_random(n, 1000 + rank * n, device=local_rank, auto_reset=True, log_capacity=args.log_capacity)
     else:
-        env = MeshVecEnv(doms, n_envs=n, env_domain=env_domain, device=local_rank, auto_reset=True, log_capacity=0)
+        env = MeshVecEnv(doms, n_envs=n, env_domain=env_domain, device=local_rank, auto_reset=True, log_capacity=args.log_capacity)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     lo = torch.tensor([-1.0, -1.5, 0.0], device=dev)
@@ -346,14 +392,21 @@ def main():
     total_steps = K * n * world
     value = total_steps / elapsed
     out = {
-        "metric": f"env-steps/sec at N_envs={n} per GPU, {wl_short} domain, {world} MI355X",
+        "metric": (f"env-steps/sec at N_envs={n * world} in all ({n} per GPU), {wl_short} domain, {world} MI355X" if strong else
+                   f"env-steps/sec at N_envs={n} per GPU, {wl_short} domain, {world} MI355X"),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n} vectorised envs per GPU on {wl}, "
                                "uniform-random float32 actions resident in HBM, auto-reset, one meshenv_step launch "
-                               "per vector step" + (f", + one async {coll} all-gather per {GS} steps of the [{GS},n,21] f32 obs/reward/done bucket written by the kernel ({n_coll} collectives covering all {n_sent} steps inside the timed region)" if do_gather else ""),
+                               "per vector step, " + (f"log_capacity={args.log_capacity} (every accepted element and created vertex is "
+                                                     "appended to the env's episode log, as generated_meshes / boundary.vertices are)"
+                                                     if args.log_capacity > 0 else
+                                                     "log_capacity=0 (element / vertex logs off: counts only)") + (f", + one async {coll} all-gather per {GS} steps of the [{GS},n,21] f32 obs/reward/done bucket written by the kernel ({n_coll} collectives covering all {n_sent} steps inside the timed region)" if do_gather else ""),
                    "n_envs_per_gpu": n, "n_envs_total": n * world, "parallelism": f"env-shard x{world}",
+                   "log_capacity": args.log_capacity,
+                   "scaling_mode": ("strong: --envs-total %d split over %d ranks" % (args.envs_total, world)) if strong else
+                                   "weak: --envs per rank",
                    "gather_every": GS if do_gather else None, "collectives": n_coll if do_gather else 0,
                    "clock_warmup_ms": args.clock_warmup_ms, "preroll_steps": args.preroll,
                    "valid_action_rate": d["valid"] / max(1, d["steps"]), "mean_ring_len": d["sum_ring"] / max(1, d["steps"])},
