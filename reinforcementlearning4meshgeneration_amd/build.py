@@ -50,6 +50,16 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)
+    # what this binary was built from (tools/source_state.py: a profile refuses to describe a library that is not the sources')
+    import hashlib
+    import json
+    h = hashlib.sha256()
+    root = os.path.dirname(PKG_DIR)
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))) + [os.path.join(root, "include", "meshenv.h")]
+    for f in files:
+        h.update(os.path.relpath(f, root).encode())
+        h.update(open(f, "rb").read())
+    json.dump({"source_sha256": h.hexdigest(), "flags": [*HIPCC_FLAGS, *extra_flags]}, open(LIB_PATH + ".source", "w"))
     return LIB_PATH
 
 

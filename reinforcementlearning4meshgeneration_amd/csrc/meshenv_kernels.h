@@ -2031,6 +2031,9 @@ __global__ void __launch_bounds__(64) k_move(DevState S, int cap, const double *
         find_next_state(c, S, bq, true, nv, n_nv, lr);
         c.ring_dirty = true;  // reference vertex, base length, action frame and observation moved: full record write-back
     }
+    // (a rejected move leaves the ring arrays as they are in HBM: only the record and the cached observation go back --
+    // until round 4 the 32 B per slot of an unchanged ring were rewritten by 80 % of the moves, 2.5x the kernel's write traffic)
+    const bool ring_unchanged = !d.ok;
     const bool none = c.ref < 0;
     const int cd = none ? (c.n > 4 ? kMoveNeedsSmoothing : kMoveNone) : kMoveOk;
     if (lane < kObsDim) obs_out[(size_t)env * kObsDim + lane] = c.obs;
@@ -2040,7 +2043,7 @@ __global__ void __launch_bounds__(64) k_move(DevState S, int cap, const double *
         code[env] = (uint8_t)cd;
         nv_count[env] = n_nv;
     }
-    store_env(c, S);
+    store_env(c, S, ring_unchanged);
 }
 
 // ------------------------------------------------------------------------------------------ CU-group step kernel

@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/prof_$tag
 rm -rf $out
 mkdir -p $out
+python3 $R/tools/source_state.py --require-fresh > $out/source_state.json || { echo "refusing to profile a stale library"; exit 1; }
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $out/pmc_fetch.log

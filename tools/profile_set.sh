@@ -2,16 +2,21 @@
 # rocprofv3 passes (kernel trace + FETCH_SIZE + WRITE_SIZE + SQ counters, each in its own run) for every workload of the
 # round besides the headline (tools/profile_round.sh does that one): gpurun_out/profset_<tag>/<key>/{trace,fetch,write,sq}
 # and <key>/line.json (the driver's JSON line).  tools/summarize_set.py <tag> turns them into profiles/<tag>_<key>_*.
-tag=${1:-r03}
+# usage: tools/profile_set.sh TAG [key ...]   (no keys: every workload)
+tag=${1:-r04}
+shift
+only=" $* "
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/profset_$tag
-rm -rf $out; mkdir -p $out
+mkdir -p $out
+python3 $R/tools/source_state.py --require-fresh > $out/source_state.json || { echo "refusing to profile a stale library"; exit 1; }
 cd /tmp
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 run() {  # key, script and arguments...
   key=$1; shift
-  mkdir -p $out/$key
+  if [ "$only" != "  " ] && [[ "$only" != *" $key "* ]]; then return; fi
+  rm -rf $out/$key; mkdir -p $out/$key
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/$key/trace -- python3 "$@" > $out/$key/line.json 2> $out/$key/trace.log
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/$key/fetch -- python3 "$@" > /dev/null 2> $out/$key/fetch.log
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/$key/write -- python3 "$@" > /dev/null 2> $out/$key/write.log

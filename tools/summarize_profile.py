@@ -25,6 +25,9 @@ def last_json_line(path):
     raise SystemExit(f"no JSON line in {path}")
 
 
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import source_state
+source = source_state.check_recorded(json.load(open(os.path.join(src, "source_state.json"))), "prof_" + tag)
 stats_csv = newest("trace/**/*_kernel_stats.csv")
 shutil.copy(stats_csv, os.path.join(dst, tag + "_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats_csv)))
@@ -80,6 +83,7 @@ summary = {
                 "beyond every cache (tools/calib_fetch.sh -> profiles/<tag>_fetch_calibration.json)"},
     "n_envs_per_gpu": line["config"]["n_envs_per_gpu"],
     "workload_key": "boundary0",
+    "source": source,
     "bench_line_under_rocprof": line_prof,
 }
 json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)

@@ -31,8 +31,14 @@ def counters(d, sub):
     return {k: {c: sum(v.values()) / len(v) for c, v in cs.items()} for k, cs in per.items()}
 
 
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import source_state
+source = source_state.check_recorded(json.load(open(os.path.join(src, "source_state.json"))), "profset_" + tag)
+
 for key in sorted(os.listdir(src)):
     d = os.path.join(src, key)
+    if not os.path.isdir(d):
+        continue
     stats = sorted(glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]
     if not stats:
         print(key, "no kernel trace"); continue
@@ -48,7 +54,7 @@ for key in sorted(os.listdir(src)):
     for sub in ("fetch", "write", "sq"):
         for k, cs in counters(d, sub).items():
             pmc.setdefault(k, {}).update(cs)
-    out = {"tag": tag, "key": key, "driver_line": {k: v for k, v in line.items() if k != "profile_kernels"}, "kernels": []}
+    out = {"tag": tag, "key": key, "source": source, "driver_line": {k: v for k, v in line.items() if k != "profile_kernels"}, "kernels": []}
     for w in want:
         cand = [r for r in rows if w["match"] in r["Name"] and (("exact" not in w) or w["exact"].replace(" ", "") in r["Name"].replace(" ", ""))]
         if not cand:
