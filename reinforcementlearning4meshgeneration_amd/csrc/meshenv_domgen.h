@@ -86,13 +86,17 @@ constexpr int kDensMaxVerts = kGenMaxVerts * 4;
 template <bool kWrite>
 __device__ __forceinline__ int density_ring(DensScratch *d, int m, double base_length, int lane, double2 *out_xy, int *status)
 {
-    bool zero = false;
+    bool zero = false, huge = false;
     for (int i = lane; i < m; i += 64) {
         const int ip = i == 0 ? m - 1 : i - 1;
         const double B = d->dens[i] * base_length, A = d->dens[ip] * base_length;
         const double L = d->L[i];
         const double xr = rint((2 * L - A - B) / (A + B));            // round(): to nearest, ties to even
-        const int x = (int)xr;
+        // an edge of more points than a whole ring may hold (or a non-finite quotient) never reaches the int conversion:
+        // (int)xr is undefined out of range, and a wrapped count would pass the size check below as a negative total
+        const bool too_many = !(xr <= (double)kDensMaxPts);
+        huge = huge || too_many;
+        const int x = too_many ? kDensMaxPts : (xr < -(double)kDensMaxPts ? -kDensMaxPts : (int)xr);
         zero = zero || x == 0;
         d->A[i] = A; d->X[i] = x;
         d->E[i] = x != 0 ? (B - A) / xr : 0.0;
@@ -102,12 +106,16 @@ __device__ __forceinline__ int density_ring(DensScratch *d, int m, double base_l
         *status = 1;
         return 0;
     }
+    if (__ballot(huge) != 0ULL) {
+        *status = 2;
+        return 0;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     int total = 0;
     if (lane == 0) {
-        int o = 0;
-        for (int i = 0; i < m; i++) { d->off[i] = o; o += d->cnt[i]; }
+        int o = 0;   // (each count <= kDensMaxPts + 1 and m <= kDensMaxVerts: the sum stays far inside int; saturate anyway)
+        for (int i = 0; i < m; i++) { d->off[i] = o; o = o > kDensMaxPts ? kDensMaxPts + 2 : o + d->cnt[i]; }
         d->off[m] = o;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -118,7 +126,7 @@ __device__ __forceinline__ int density_ring(DensScratch *d, int m, double base_l
     const bool pop = (total & 1) != 0;
     const int pop_at = last_len / 2;
     const int n_out = total - (pop ? 1 : 0);
-    if (n_out > kDensMaxPts) {
+    if (n_out > kDensMaxPts || n_out <= 0) {
         *status = 2;
         return 0;
     }
@@ -382,7 +390,9 @@ __device__ __forceinline__ int gen_ring(GenScratch *g, const GenParams &P, unsig
         }
         if (lane == 0) {
             if (st == 1 && P.raises) P.raises[ring_index] = 1;
-            if (st >= 2) atomicOr(err, 4);
+            // (with a flag array every failure is reported per ring -- 2 = "not generated here": a ring beyond 2048 points,
+            // an edge outside the direction table -- so that a probe over many seeds can leave exactly those seeds out)
+            if (st >= 2) { if (P.raises) P.raises[ring_index] = 2; else atomicOr(err, 4); }
             if (st == 1 && !P.raises) atomicOr(err, 8);
         }
         return c;

@@ -656,8 +656,10 @@ static int create_random_impl(const char *fn, int device, int n_envs, GenParams 
     }
     if (n_raise) {
         cleanup();
-        g_create_error = std::string(fn) + ": calculate_density raises ZeroDivisionError for " + std::to_string(n_raise) + " of " +
-                         std::to_string(n_envs) + " polygons (an edge of 0.5 - 1.5 spacings, ui/tk-ui.py:263-264): see raises_host and pass seeds without them";
+        g_create_error = std::string(fn) + ": " + std::to_string(n_raise) + " of " + std::to_string(n_envs) +
+                         " polygons have no ring here -- raises_host[k] = 1: calculate_density raises ZeroDivisionError (an edge of "
+                         "0.5 - 1.5 spacings, ui/tk-ui.py:263-264); 2: not generated on the device (fewer than 5 distinct pixels, a "
+                         "densified ring beyond 2048 points, an edge outside the direction table) -- pass seeds without them";
         return MESHENV_E_STATE;
     }
     if (!out) { cleanup(); return MESHENV_OK; }   // probe only

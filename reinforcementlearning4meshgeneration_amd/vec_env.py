@@ -237,6 +237,8 @@ class MeshVecEnv:
                     rz = np.zeros(blk, np.uint8)
                     rc = L.meshenv_create_random_density(device, blk, C.c_uint64(nxt), None, int(num_verts), float(base_length),
                                                          float(density), None, C.c_void_p(stream), None, rz.ctypes.data)
+                    # E_STATE with flags set = some seeds of the block have no ring (flag 1: calculate_density raises, flag 2:
+                    # not generated on the device): exactly those are left out; anything else is an error of the call itself
                     if rc not in (0, _capi.E_STATE) or (rc == _capi.E_STATE and not rz.any()):
                         msg = L.meshenv_last_error(None)
                         raise _capi.MeshEnvError(f"meshenv_create_random_density (probe) failed (code {rc}): {msg.decode() if msg else ''}")

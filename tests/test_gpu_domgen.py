@@ -206,3 +206,35 @@ def test_device_density_mode_equals_host_restatement_on_generated_polygons():
         env.step((lo + (hi - lo) * torch.rand((512, 3), device="cuda", generator=g)).contiguous())
     assert env.counters()["valid"] - valid0 > 200       # the rings are meshable domains
     env.close()
+
+
+def test_density_rings_extreme_spacings_are_reported_not_written():
+    """meshenv_density_rings accepts pixel coordinates up to 1e9 and any base_length > 0: an edge whose point count exceeds a
+    whole ring (or the int range) must come back as status 2, never as a write past the 2048-point staging array."""
+    from reinforcementlearning4meshgeneration_amd import domains as D
+    far = [(0, 0), (900_000_000, 0), (900_000_000, 900_000_000), (0, 900_000_000)]
+    rings, st = D.device_density_rings([far, far, [(0, 0), (400, 0), (400, 400), (0, 400)]], 1e-6)
+    assert list(st) == [2, 2, 2] and all(r is None for r in rings)
+    rings, st = D.device_density_rings([far, [(0, 0), (400, 0), (400, 400), (0, 400)]], 20.0)
+    assert st[0] == 2 and st[1] == 0 and rings[1].shape[0] == 80       # the neighbour of a refused ring is still produced
+
+
+def test_random_density_probe_skips_seeds_the_device_cannot_generate():
+    """from_random_density at a spacing where some generated polygons densify beyond 2048 points: those seeds are flagged per
+    ring (2) and left out by the probe; the envs are built from the others; naming a flagged seed explicitly is an error
+    that lists it."""
+    import ctypes as C
+    from reinforcementlearning4meshgeneration_amd import MeshVecEnv, _capi
+    L = _capi.load()
+    base_length, seed0, blk = 0.6, 40_000, 512
+    rz = np.zeros(blk, np.uint8)
+    rc = L.meshenv_create_random_density(0, blk, C.c_uint64(seed0), None, 0, base_length, 1.0, None, None, None, rz.ctypes.data)
+    assert rc == _capi.E_STATE and (rz == 2).any() and (rz == 0).any(), np.bincount(rz, minlength=3)
+    env = MeshVecEnv.from_random_density(64, seed0, base_length=base_length)
+    flagged = set((seed0 + np.nonzero(rz != 0)[0]).tolist())
+    assert len(env.seeds) == 64 and not (set(env.seeds.tolist()) & flagged)
+    assert env.max_ring <= 2048 and env.get_domain(0)[0].shape[0] >= 4
+    env.close()
+    bad = seed0 + int(np.nonzero(rz == 2)[0][0])
+    with pytest.raises(_capi.MeshEnvError, match=str(bad)):
+        MeshVecEnv.from_random_density(2, 0, base_length=base_length, seeds=[int(env.seeds[0]), bad])
