@@ -174,7 +174,12 @@ int meshenv_group_size(const MeshEnv *h);
  * 3 = k_step<false, ., true>: after a front smoothing (meshenv_smooth with interior = 0, or a meshenv_move that went through
  * smooth_pave) and until the next reset of ALL envs rings may hold vertices off the 1e-4 lattice, whose clockwise angles
  * can sit exactly on a rounding boundary; steps then run the one-wave-per-env kernel in the instantiation that decides
- * those like the reference's libm (meshenv_atan2_exact). */
+ * those like the reference's libm (meshenv_atan2_exact).
+ * 4 = k_step_group<16, ., true>: the CU-group kernel with its LDS packed by each ring's own length (batches of mixed
+ * domains whose sixteen longest rings would not fit one CU).  5 = k_step_group<G, ., false, true>: the CU-group kernel of
+ * batches whose ring stride is at most 64 slots (every ring pass is one 64-lane pass, no chunk loops).
+ * 6 = k_step<false, true, false, true>: the one-wave-per-env kernel of such batches (default geometry constants).
+ * (2 exists in -DMESHENV_DEV builds of the library only.) */
 int meshenv_step_kernel(const MeshEnv *h);
 /* The smoothing kernels evaluate `x ** 2` like the reference's libm (CPython's float ** 2 is pow(x, 2.0), which glibc does
  * not round correctly: it differs from x * x in 0.085 % of the arguments) through a restatement of glibc's pow

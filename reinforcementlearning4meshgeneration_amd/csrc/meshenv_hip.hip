@@ -443,6 +443,7 @@ static int create_impl(int device, int n_domains, const int32_t *dom_offsets_hos
             const bool ragged = !h->env_lds_host.empty();
             const void *fn = ragged ? (const void *)k_step_group<16, true, true>
                              : G == 16 ? (const void *)k_step_group<16, true> : (const void *)k_step_group<8, true>;
+            if (!ragged && cap <= 64) fn = G == 16 ? (const void *)k_step_group<16, true, false, true> : (const void *)k_step_group<8, true, false, true>;
 #ifdef MESHENV_DEV
             if (G == 4) fn = (const void *)k_step_group<4, true>;
 #endif
@@ -847,7 +848,18 @@ int meshenv_set_packed_output(MeshEnv *h, float *msg_dev)
 int meshenv_num_envs(const MeshEnv *h) { return h ? h->n_envs : MESHENV_E_ARG; }
 int meshenv_max_ring(const MeshEnv *h) { return h ? h->max_ring : MESHENV_E_ARG; }
 int meshenv_group_size(const MeshEnv *h) { return h ? h->group : MESHENV_E_ARG; }
-int meshenv_step_kernel(const MeshEnv *h) { return h ? (h->front_moved ? 3 : (h->group > 1 ? (h->spec ? 2 : 1) : 0)) : MESHENV_E_ARG; }
+int meshenv_step_kernel(const MeshEnv *h)
+{
+    if (!h) return MESHENV_E_ARG;
+    if (h->front_moved) return 3;
+    if (h->group <= 1) return (h->default_params && h->cap <= 64) ? 6 : 0;
+    if (h->spec) return 2;
+    if (h->env_lds) return 4;
+#ifdef MESHENV_DEV
+    if (h->group == 4) return 1;
+#endif
+    return h->cap <= 64 ? 5 : 1;
+}
 int meshenv_libm_exact(const MeshEnv *h) { return h ? h->libm_exact : MESHENV_E_ARG; }
 int meshenv_atan2_exact(void) { return atan_host().mode == 2 ? 1 : 0; }
 
@@ -1205,6 +1217,8 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         else
 #endif
         if (h->env_lds) hipLaunchKernelGGL((k_step_group<16, true, true>), grid, block, h->group_lds, h->stream, A);   // ragged: G == 16 only
+        else if (h->cap <= 64 && G == 16) hipLaunchKernelGGL((k_step_group<16, true, false, true>), grid, block, h->group_lds, h->stream, A);
+        else if (h->cap <= 64) hipLaunchKernelGGL((k_step_group<8, true, false, true>), grid, block, h->group_lds, h->stream, A);
         else if (G == 16) hipLaunchKernelGGL((k_step_group<16, true>), grid, block, h->group_lds, h->stream, A);
         else hipLaunchKernelGGL((k_step_group<8, true>), grid, block, h->group_lds, h->stream, A);
     } else {
@@ -1216,6 +1230,7 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         ka.reward = reward_dev; ka.done = done_dev; ka.complete = complete_dev; ka.term_obs = terminal_obs_dev;              \
         ka.auto_reset = auto_reset; ka.step0 = (unsigned long long)h->steps_done;                                            \
         if (h->front_moved) hipLaunchKernelGGL((k_step<MULTI, DEF, true>), grid, block, h->lds, h->stream, ka);              \
+        else if (DEF && h->cap <= 64) hipLaunchKernelGGL((k_step<MULTI, DEF, false, DEF>), grid, block, h->lds, h->stream, ka); \
         else hipLaunchKernelGGL((k_step<MULTI, DEF>), grid, block, h->lds, h->stream, ka);                                   \
     } while (0)
         if (n_steps == 1) {

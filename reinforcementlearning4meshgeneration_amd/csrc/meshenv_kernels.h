@@ -401,6 +401,8 @@ __device__ __forceinline__ double dist_lr(const LibmRef lr, P2 a, P2 b)
     return sqrt_pos(pow2_nc(a.x - b.x) + pow2_nc(a.y - b.y));
 }
 
+__device__ __forceinline__ int nf_compact(Ctx &c, bool near, int i, int count);   // (below: survivors of a 64-lane chunk -> c.list)
+
 __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArgs &bq, const bool is_static = false,
                                                 const double2 *nv = nullptr, int n_nv = 0, const LibmRef lr = LibmRef{nullptr, 0})
 {
@@ -534,11 +536,46 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     const bool bq_scan = bq.mode == 1 && !bq.skip;
     const P2 add_v = ldp(c, bq_scan ? bqi : 0);
     const DistThr dst_thr = dist_thr(dst);
-    // traversal positions stage A had no lane for (rings longer than 58): their clockwise angles in full 64-lane
-    // passes of their own, so that a 120-vertex ring costs one more transcendental pass, not two
-    for (int o0 = kScanLanes; o0 < n - 1; o0 += 64) {
-        const int o = o0 + lane;
-        const bool in = o < n - 1;
+    // Rings of several 64-vertex chunks (d1 / d2 / d3: 120 / 196 / 272 vertices): an EXACT pre-filter, the survivors
+    // compacted (c.list, in traversal order), and the scan itself -- its clockwise angle, the fan-slot test, the bisector's
+    // intersection quotients -- once over the survivors instead of once per chunk.  What a position can contribute:
+    //  * a fan slot needs d(ref, v) < target_length, hence |v.x - ref.x| < target_length (1 + 2^-52);
+    //  * a hit of the bisector needs 0 < s < 1 and 0 < h < 1 AS COMPUTED, with h = fl(fl(r + fl(s u)) / w) in the x
+    //    coordinate (r = ref.x - v.x, w = b.x - v.x, u = p_s.x - ref.x) in the general and the w.y == 0 branch: then
+    //    fl(r + fl(s u)) lies between 0 and w up to a rounding, i.e. ref.x + s u lies in the edge's x-extent widened by
+    //    4 ulp of (|r| + |u|), and with 0 < s < 1 it also lies in ref.x +- |u|, |u| <= target_length (1 + 2^-50); in the
+    //    w.x == 0 branch s = fl((v.x - ref.x) / u) in (0, 1) says the same of v.x = b.x directly.
+    // So a position whose edge has no x in common with the slab ref.x +- W, W = target_length (1 + 1e-9) + 1e-9, changes
+    // nothing, whatever its (possibly ill-conditioned) quotients evaluate to; NaN coordinates fail every comparison in
+    // both forms.  -DMESHENV_NO_FILTERS builds the unfiltered scan.  (Rings of at most 65 vertices: every position is
+    // scanned, in place -- `count` = n - 1 positions, position j IS traversal order j.)
+#ifdef MESHENV_NO_FILTERS
+    const bool long_ring = false;
+#else
+    const bool long_ring = n - 1 > 64;
+#endif
+    int count = n - 1;
+    if (long_ring) {
+        const double W = target_length * (1 + 1e-9) + 1e-9;
+        const double slab_lo = ref.x - W, slab_hi = ref.x + W;
+        int m = 0;
+        for (int base = 0; base < n - 1; base += 64) {
+            const int ord = base + lane;
+            const bool in = ord < n - 1;
+            const int ii = wrapi(idc - 1 - (in ? ord : 0), n);
+            const P2 v = ldp(c, ii), b = ldp(c, wrapi(ii + 1, n));
+            const double xlo = v.x < b.x ? v.x : b.x, xhi = v.x < b.x ? b.x : v.x;
+            m = nf_compact(c, in && xlo <= slab_hi && xhi >= slab_lo, ord, m);
+        }
+        count = m;
+        wave_sync();
+    }
+    // the clockwise angles of the scanned positions stage A had no lane for (rings longer than 58), in full 64-lane passes
+    // of their own: a 120-vertex ring costs one more transcendental pass, not two
+    for (int a0 = long_ring ? 0 : kScanLanes; a0 < count; a0 += 64) {
+        const bool in_list = a0 + lane < count;
+        const int o = long_ring ? c.list[in_list ? a0 + lane : 0] : a0 + lane;
+        const bool in = in_list && o >= kScanLanes;
         double cc, dd;
         cw_terms(ref, ldp(c, wrapi(idc - 1 - (in ? o : 0), n)), right, cc, dd);
 #ifdef MESHENV_NO_FILTERS
@@ -552,13 +589,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
     }
     wave_sync();
     for (int base = 0; base < n; base += 64) {
-        // (1) observation scan
-        const int ord = base + lane;
-        const bool in_range = ord < n - 1;
-        const int ii = wrapi(idc - 1 - (in_range ? ord : 0), n);
-        const P2 v = ldp(c, ii);
-        const double angle = in_range ? c.ang_ord[ord] : 0.0;
-        // (2) boundary-quality scan (mode 1): added(i) = near(i) && !added(i-1), M:355-357
+        // (2) boundary-quality scan (mode 1) of ring index base + lane: added(i) = near(i) && !added(i-1), M:355-357
         if (bq_scan) {
             const int i = base + lane;
             bool near = false;
@@ -580,6 +611,13 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
             }
             carry = (int)((__ballot(added) >> 63) & 1ULL);
         }
+        if (base >= count) continue;   // (wave-uniform: a pre-filtered ring has fewer positions to scan than vertices)
+        // (1) observation scan of scanned position base + lane
+        const bool in_range = base + lane < count;
+        const int ord = long_ring ? c.list[in_range ? base + lane : 0] : base + lane;
+        const int ii = wrapi(idc - 1 - (in_range ? ord : 0), n);
+        const P2 v = ldp(c, ii);
+        const double angle = in_range ? c.ang_ord[ord] : 0.0;
         const bool live = in_range && ii != i_right && ii != i_left && angle != 0.0;
         if (live) {
             const double d = dist_lr(lr, ref, v);
@@ -587,7 +625,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
             if (kf < 3.0 && d < target_length) {
                 const int k = (int)kf;
                 const float cnd = (float)((d / radius) / bl);
-                const u64 key = ((u64)__float_as_uint(cnd) << 32) | (unsigned)ord;  // ord increases per lane: '<' keeps the first
+                const u64 key = ((u64)__float_as_uint(cnd) << 32) | (unsigned)ord;  // keys order by (value, traversal order): '<' keeps the first
                 if (k == 0) k0 = key < k0 ? key : k0;
                 else if (k == 1) k1 = key < k1 ? key : k1;
                 else k2 = key < k2 ? key : k2;
@@ -611,6 +649,7 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
             }
         }
     }
+    const bool ang_all = !long_ring;   // c.ang_ord holds the angle of every traversal position (false: of the scanned ones only)
     MESHENV_STAMP(c, 12);
     // ---- reductions: first-wins minima as packed (value bits, order) keys, one interleaved DPP scan
     u64 rk = (u64)__double_as_longlong(rbest), mk = (u64)__double_as_longlong(m_d);
@@ -659,8 +698,17 @@ __device__ __forceinline__ void find_next_state(Ctx &c, const DevState &S, BqArg
         float fa = (float)fmin(((2 * j + 1) * theta) / 6, clipmax);  // default [1, clip((2j+1)*theta/6)]
         if (use_hit) {
             const int ov = (int)ro + 1 - j;  // ring[_i - 1 + j] in traversal order
-            fd = (float)((dist_lr(lr, ref, ldp(c, wrapi(idc - 1 - ov, n))) / radius) / bl);
-            fa = (float)c.ang_ord[ov];
+            const P2 hv = ldp(c, wrapi(idc - 1 - ov, n));
+            fd = (float)((dist_lr(lr, ref, hv) / radius) / bl);
+            // (pre-filtered scan: the two neighbours of the hit edge's first vertex need not have been scanned -- positions
+            // -1 and n - 1 are the reference vertex's neighbours and itself, whose angles the reference takes as well)
+            if (ang_all) {
+                fa = (float)c.ang_ord[ov];
+            } else {
+                double cc, dd;
+                cw_terms(ref, hv, right, cc, dd);
+                fa = (float)cw_sel(c.tie, cc, dd);
+            }
         } else if (sw < 1.0f) {
             fd = sw;
             fa = (float)fmin(c.ang_ord[ow], clipmax);
@@ -1769,13 +1817,15 @@ __device__ __forceinline__ KStepArgs late_kstep_args()
 #endif
 // (kTie: the handle has smoothed a front -- its rings hold vertices off the 1e-4 lattice and half-quantum angles, so the
 // angles take the tie-breaking atan2 of the move() path, csrc/meshenv_geom.h; the host then steps with these instantiations)
-template <bool kMulti, bool kDefaultParams, bool kTie = false>
+// (kSmall: ring stride <= 64, as in step_group_body -- every ring pass is one 64-lane pass)
+template <bool kMulti, bool kDefaultParams, bool kTie = false, bool kSmall = false>
 __global__ void __launch_bounds__(64, MESHENV_STEP_WAVES_PER_SIMD)
 k_step(const KStepArgs A)
 {
     // (one by-value argument block: its layout IS the kernel-argument segment that late_kstep_args reads again)
     DevState S = A.S;
     const int cap = A.cap, n_steps = A.n_steps;
+    if (kSmall) __builtin_assume(cap <= 64 && S.cap <= 64 && cap > 0 && S.cap > 0);   // no second chunk in the loads either
     const float *__restrict__ actions = A.actions;
     float *__restrict__ obs_out = A.obs_out;
     double *__restrict__ reward = A.reward;
@@ -1836,6 +1886,7 @@ k_step(const KStepArgs A)
 #endif
     if (light) load_env(c, S, env, false);
     else load_env(c, S, env);
+    if (kSmall) __builtin_assume(c.n <= 64 && c.n >= 0);
 #ifdef MESHENV_STAMPS
     const unsigned long long stamp_t1 = __builtin_amdgcn_s_memrealtime();
     if (c.lane < 16) c.sc->stamps[c.lane] = 0;
@@ -1860,6 +1911,7 @@ k_step(const KStepArgs A)
             const float *at = actions + ((size_t)t * E + env) * 3;
             a0 = at[0]; a1 = at[1]; a2 = at[2];
         }
+        if (kSmall) __builtin_assume(c.n <= 64 && c.n >= 0);   // (again per iteration: an extraction / a reset has rewritten n)
         const int n_before = c.n;
         // env_step, with the keys of a ring staged without them fetched between the checks and the update
         Decision d = env_check(c, S, a0, a1, a2, kMulti);
@@ -2206,7 +2258,9 @@ __device__ __forceinline__ void finish_and_store(Ctx &c, const DevState &S_in, c
 // (actor_in: k_step_group_actor only -- LDS [G][132] floats, the actor's first-layer input; nullptr otherwise)
 // (kRagged: the workgroup's LDS is packed by each env's own ring length, GroupArgs::env_lds -- batches of mixed domains only;
 // the uniform instantiation holds no offset table, no per-env region lookup and no Handoff fields for them)
-template <int G, bool kDefaultParams, bool kRagged = false>
+// (kSmall: the batch's ring stride is at most 64 slots, so every ring fits one 64-lane pass: the compiler is told n <= 64 and
+// drops the chunk loops of every ring pass and the multi-chunk forms behind them -- 8864 -> 7621 static instructions)
+template <int G, bool kDefaultParams, bool kRagged = false, bool kSmall = false>
 __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor_in = nullptr, const int tstep = 0,
                                                 KernArgPtr ka = nullptr, const int tid_in = -1)
 {
@@ -2215,6 +2269,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     extern __shared__ double2 smem[];
     DevState S = A.S;
     const int cap = A.cap, auto_reset = A.auto_reset;
+    if (kSmall) __builtin_assume(cap <= 64 && S.cap <= 64 && cap > 0 && S.cap > 0);   // no second chunk in the loads either
     const float *__restrict__ actions = A.actions;
     if (kDefaultParams) apply_default_params(S.prm);
     const int wave = uniform_i32(tid >> 6);  // wave-uniform by construction: keeps env and every address derived from it in SGPRs
@@ -2244,6 +2299,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
         cnt0.last_change = 0; cnt0.valid = 0; cnt0.sum_n = 0; cnt0.sum_n_valid = 0;
         constexpr bool kCntLate = true;
         load_env(c, S, env, true, tid_in >= 0 ? (tid & 63) : -1, kRagged ? my_cap : 0);
+        if (kSmall) __builtin_assume(c.n <= 64 && c.n >= 0);
         const int n_before = c.n;
         Decision d = env_check(c, S, a0, a1, a2, false, false, 0.0, 0.0, 0.5, nullptr, true);
         if (!d.ok) {
@@ -2378,6 +2434,7 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
     c.env = uniform_i32(h.env);
     c.base = (size_t)c.env * S.cap;
     c.n = uniform_i32(h.n); c.ref = uniform_i32(h.ref); c.n_elem = uniform_i32(h.n_elem); c.failed = uniform_i32(h.failed);
+    if (kSmall) __builtin_assume(c.n <= 64 && c.n >= 0);
     c.n_new = uniform_i32(h.n_new); c.counter = uniform_i32(h.counter); c.status = uniform_i32(h.status); c.dom = uniform_i32(h.dom);
     c.bl = uniform_f64(h.bl); c.area = uniform_f64(h.area); c.ct = uniform_f64(h.ct); c.st = uniform_f64(h.st);
     c.ring_dirty = false;
@@ -2412,11 +2469,11 @@ __device__ __forceinline__ void step_group_body(const GroupArgs &A, float *actor
 }
 
 
-template <int G, bool kDefaultParams, bool kRagged = false>
+template <int G, bool kDefaultParams, bool kRagged = false, bool kSmall = false>
 __global__ void __launch_bounds__(64 * G)
 k_step_group(GroupArgs A)
 {
-    step_group_body<G, kDefaultParams, kRagged>(A);
+    step_group_body<G, kDefaultParams, kRagged, kSmall>(A);
 }
 
 // ------------------------------------------------------------------------------------------ speculative CU-group kernel

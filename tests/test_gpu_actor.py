@@ -96,7 +96,7 @@ def test_fused_step_and_actor_equals_the_two_launch_path():
         ls.bias.fill_(-0.5)
     actor = FusedActor.from_torch(lin, mu, ls)
     d1 = [tuple(p) for p in np.load(os.path.join(GOLDEN_DIR, "boundary16_biased_s2.npz"))["domain_xy"]]
-    for n, want_kernel in ((4096, "meshenv::k_step_group<16, true>"), (2048, None)):
+    for n, want_kernel in ((4096, "meshenv::k_step_group<16, true, false, false>"), (2048, None)):
         a_env = MeshVecEnv([d1], n_envs=n)
         b_env = MeshVecEnv([d1], n_envs=n)
         if want_kernel:

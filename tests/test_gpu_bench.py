@@ -53,4 +53,4 @@ def test_bench_line_states_log_capacity_scaling_and_cpu_quota():
     if allc["cgroup_cpu_quota"] is not None:
         assert allc["cores"] == min(allc["cgroup_cpu_quota"], allc["sched_getaffinity"])
     r = line["roofline"]
-    assert r["kernel"] == "meshenv::k_step_group<16, true>" and 5 < r["kernel_avg_us"] < 40 and 0 < r["frac"] < 1
+    assert r["kernel"] == "meshenv::k_step_group<16, true, false, true>" and 5 < r["kernel_avg_us"] < 40 and 0 < r["frac"] < 1

@@ -115,7 +115,7 @@ def test_config4_mixed_d1_d2_d3_one_gpu_share(torch_cuda):
     # steps with the CU-group kernel, its LDS packed by ring length (csrc/meshenv_kernels.h, GroupArgs::env_lds)
     from reinforcementlearning4meshgeneration_amd import MeshVecEnv
     probe = MeshVecEnv(doms, env_domain=env_domain)
-    assert probe.step_kernel == "meshenv::k_step_group<16, true>"
+    assert probe.step_kernel == "meshenv::k_step_group<16, true, true, false>"
     probe.close()
 
 
@@ -146,7 +146,7 @@ def test_config4_full_size_32768_mixed_envs_sampled_oracle_shadow(torch_cuda):
     n, T, S = 32768, 32, 768
     env_domain = (np.arange(n) % 3).astype(np.int32)
     env = MeshVecEnv(doms, env_domain=env_domain)
-    assert env.step_kernel == "meshenv::k_step<false, true, false>"
+    assert env.step_kernel == "meshenv::k_step<false, true, false, false>"
     pick = np.arange(0, n, n // S)[:S] + np.arange(S) % 3          # all three domains in the sample
     pick = np.unique(np.clip(pick, 0, n - 1))
     batch = RefBatch([RefEnv.from_points(doms[env_domain[k]], cap_new=64) for k in pick])

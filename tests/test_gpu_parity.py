@@ -307,7 +307,7 @@ def test_record_first_staging_equals_full_staging(torch_cuda, monkeypatch):
     env_domain = (np.arange(n) % len(doms)).astype(np.int32)
     full = MeshVecEnv(doms, env_domain=env_domain)
     lazy = MeshVecEnv(doms, env_domain=env_domain)
-    assert full.step_kernel == "meshenv::k_step<false, true, false>"
+    assert full.step_kernel.startswith("meshenv::k_step<false, true, false")
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     lo = torch.tensor([-1.0, -1.5, 0.0], device="cuda"); hi = torch.tensor([1.0, 1.5, 1.5], device="cuda")
     truncated = 0

@@ -344,19 +344,19 @@ def test_steps_after_a_front_smoothing_run_the_tie_breaking_kernel(torch_cuda):
             assert np.array_equal(d[idx].cpu().numpy(), d_ref) and np.array_equal(c[idx].cpu().numpy(), c_ref)
             differing[0] += int((o[idx].cpu().numpy() != o_ref.astype(np.float32)).sum())
 
-    assert L.meshenv_step_kernel(h) == 1
+    assert L.meshenv_step_kernel(h) in (1, 5)      # a CU-group kernel (5: ring stride <= 64)
     steps(40)
     sweeps, _ = env.smooth_pave(iteration=400, interior=False)
     obs_after = env.obs[idx].cpu().numpy()
     for j in range(S):
         code, sw, o_ref = refs[j].smooth_pave_full(400)
         assert code == 0 and sw == int(sweeps[pick[j]]) and np.array_equal(obs_after[j], o_ref.astype(np.float32)), j
-    assert L.meshenv_step_kernel(h) == 3 and env.step_kernel == "meshenv::k_step<false, true, true>"
+    assert L.meshenv_step_kernel(h) == 3 and env.step_kernel == "meshenv::k_step<false, true, true, false>"
     steps(60)
     assert differing[0] == 0
     env.reset()
     batch.reset()
-    assert L.meshenv_step_kernel(h) == 1
+    assert L.meshenv_step_kernel(h) in (1, 5)      # a CU-group kernel (5: ring stride <= 64)
     steps(10)
     assert differing[0] == 0
     env.close()

@@ -59,7 +59,7 @@ def _run(lib):
 
 def test_no_helper_and_no_filters_builds_agree_with_the_default_library():
     base = _run(None)
-    assert base["kernel"] == "meshenv::k_step_group<16, true>" and base["valid"] > 0.1 * 4096 * 64
+    assert base["kernel"] == "meshenv::k_step_group<16, true, false, true>" and base["valid"] > 0.1 * 4096 * 64
     for name, flags in (("nohelper", ["-DMESHENV_NO_HELPER"]), ("nofilters", ["-DMESHENV_NO_FILTERS"])):
         res = _run(_build(name, flags))
         assert res["valid"] == base["valid"] and res["obs_mismatch"] == 0, (name, res)
