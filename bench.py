@@ -41,11 +41,14 @@ def pmc_traffic(n_envs, workload="boundary0"):
     gfx950.  None when no profile of this workload is committed (bench.py cannot run the profiler on itself)."""
     d, src = committed_profile(n_envs, workload)
     if d is None:
-        return None, None
+        return None, None, None
     t = d["hbm_traffic_bytes_per_launch"]
-    # the calibrated figure (FETCH_SIZE weighted by the factor measured for this kernel's load mix) where the profile has it,
-    # else the guide's 2x correction (an upper bound here)
-    return t.get("calibrated_(f*FETCH+WRITE)*1024") or t["gfx950_corrected_(2*FETCH+WRITE)*1024"], src
+    # `traffic` is the guide's figure (2 x FETCH_SIZE + WRITE_SIZE: an upper bound for this kernel, whose loads mix 16-, 8- and
+    # 4-byte-per-lane widths); the calibrated figure (FETCH_SIZE weighted by the factor measured for exactly this load mix,
+    # tools/calib_fetch.sh) and the raw one are reported beside it, never instead of it
+    return t["gfx950_corrected_(2*FETCH+WRITE)*1024"], src, {"calibrated": t.get("calibrated_(f*FETCH+WRITE)*1024"),
+                                                             "fetch_calibration_factor": t.get("fetch_calibration_factor"),
+                                                             "raw_FETCH+WRITE": t.get("raw_(FETCH+WRITE)*1024")}
 
 
 def committed_profile(n_envs, workload):
@@ -421,12 +424,13 @@ def main():
         avg_ms = min_ms = 1e3 * elapsed / K
         n_timed, timing = K, "wall (no HIP-event group recorded): elapsed / steps, includes host launch gaps"
     achieved = alg / (avg_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(n, args.workload)
+    traffic, traffic_src, traffic_alt = pmc_traffic(n, args.workload)
     # "bound" names the roofline the fraction is priced against (the contract's hbm | mfma; this path has no contraction);
     # "limited_by" says what the counters show the kernel is actually held by
     out["roofline"] = {"bound": "hbm", "limited_by": "instruction issue / dependent-issue latency, not HBM (instruction_side)",
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                       "traffic_over_algorithmic": (traffic / alg) if traffic else None, "traffic_other_readings": traffic_alt,
                        "kernel": env.step_kernel,
                        "kernel_avg_us": avg_ms * 1e3, "kernel_min_us": min_ms * 1e3,
                        "algorithmic_bytes_per_launch": alg, "launches_timed": n_timed, "timing": timing,

@@ -31,14 +31,14 @@ __host__ __device__ __forceinline__ size_t group_actor_lds_bytes(int cap)
     return group_lds_bytes(cap, 16) + sizeof(float) * kActorLdsFloats;
 }
 
-template <bool kDefaultParams>
+template <bool kDefaultParams, bool kSmall = false>
 __global__ void __launch_bounds__(64 * 16)
 k_step_group_actor(GroupActorArgs A)
 {
     extern __shared__ double2 smem[];
     float *lds = (float *)((char *)smem + group_lds_bytes(A.g.cap, 16));
     // every wave writes the observation its step ends with into the actor's input row as well (finish_and_store)
-    step_group_body<16, kDefaultParams>(A.g, lds);   // (returns for every wave: nothing exits before the barrier)
+    step_group_body<16, kDefaultParams, false, kSmall>(A.g, lds);   // (returns for every wave: nothing exits before the barrier)
     ActorHead hd;
     actor_request_weights(hd, A.W, threadIdx.x, true);   // all three layers: in flight while the workgroup's slowest wave finishes
     __syncthreads();

@@ -1781,6 +1781,7 @@ int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float
     MESHENV_ON_DEVICE(h);
     if (!h->fused_ready) {
         HIP_TRY(h, hipFuncSetAttribute((const void *)k_step_group_actor<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(h, hipFuncSetAttribute((const void *)k_step_group_actor<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         h->fused_ready = true;
     }
     GroupActorArgs GA;
@@ -1797,7 +1798,8 @@ int meshenv_step_actor(MeshEnv *h, MeshActor *a, const float *actions_dev, float
     GA.eps_out = eps_out_dev;
     GA.seed = seed; GA.counter = counter;
     GA.sample = sample ? 1 : 0; GA.pad = 0;
-    hipLaunchKernelGGL((k_step_group_actor<true>), dim3((h->n_envs + 15) / 16), dim3(64 * 16), group_actor_lds_bytes(h->cap), h->stream, GA);
+    if (h->cap <= 64) hipLaunchKernelGGL((k_step_group_actor<true, true>), dim3((h->n_envs + 15) / 16), dim3(64 * 16), group_actor_lds_bytes(h->cap), h->stream, GA);
+    else hipLaunchKernelGGL((k_step_group_actor<true>), dim3((h->n_envs + 15) / 16), dim3(64 * 16), group_actor_lds_bytes(h->cap), h->stream, GA);
     HIP_TRY(h, hipGetLastError());
     h->steps_done += 1;
     return MESHENV_OK;

@@ -1,4 +1,4 @@
-"""CPU: the bench.py output contract, checked on the committed line of the round (profiles/r03_bench_line.json) and on
+"""CPU: the bench.py output contract, checked on the committed line of the round (profiles/r04_bench_line.json) and on
 bench.py's own argument defaults -- the driver parses exactly these keys."""
 import importlib.util
 import json
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_line.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -24,7 +24,12 @@ def test_committed_bench_line_has_the_contract_keys():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and "not HBM" in r["limited_by"]
     # no published number in BASELINE.md -> vs_baseline null; the ratio to the CPU baseline of the same run has its own key
     assert abs(d["vs_cpu_baseline"]["all_cores"] - d["value"] / d["cpu_baseline"]["all_cores"]["value"]) < 1e-9
-    assert d["cpu_baseline"]["all_cores"]["sched_getaffinity"] >= d["cpu_baseline"]["all_cores"]["cores"] >= 1
+    allc = d["cpu_baseline"]["all_cores"]
+    assert allc["sched_getaffinity"] >= allc["cores"] >= 1
+    # the all-cores leg runs at min(cgroup quota, affinity) threads and says so
+    assert allc["cgroup_cpu_quota"] is None or allc["cores"] == min(allc["cgroup_cpu_quota"], allc["sched_getaffinity"])
+    assert "one parallel region" in allc["openmp_schedule"]
+    assert "log_capacity=0" in d["config"]["workload"] and d["config"]["log_capacity"] == 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0
     assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.5
     c = d["cpu_baseline"]
@@ -35,7 +40,7 @@ def test_committed_bench_line_has_the_contract_keys():
     # value is consistent with the step time and the env count
     assert abs(d["value"] - d["config"]["n_envs_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     # the rocprof summary of the same command agrees with the live event timing within 5 %
-    s = json.load(open(os.path.join(ROOT, "profiles", "r03_summary.json")))
+    s = json.load(open(os.path.join(ROOT, "profiles", "r04_summary.json")))
     assert abs(s["kernel_trace"]["avg_ns"] / 1e3 - r["kernel_avg_us"]) / r["kernel_avg_us"] < 0.05
     assert s["kernel"].replace(" ", "") == r["kernel"].replace(" ", "")
 

@@ -108,6 +108,13 @@ if __name__ == "__main__":
         mdoms = [boundary(0), boundary(-1), boundary(1), boundary(2)] + [golden_domain(x) for x in ("boundary16_biased_s2", "random1_1_biased_s1", "star_biased_s6")] + [random_domain(7000 + dom_off + k) for k in range(25)]
         move_campaign("move() x2048 on 32 domains", mdoms, (np.arange(2048) % len(mdoms)).astype(np.int32), int(60 * scale), 105 + seed_off)
         sys.exit(0)
+    if "--long-only" in sys.argv:   # rings of several 64-vertex chunks only (the pre-filtered observation scan), other seeds
+        big = [golden_domain(x) for x in ("boundary16_biased_s2", "boundary15_biased_s5", "test1_biased_s42", "dolphine3_biased_s0", "random1_1_biased_s1")]
+        campaign("5 long shipped domains x2045 biased", big, (np.arange(2045) % 5).astype(np.int32), int(300 * scale), 203 + seed_off, True)
+        campaign("5 long shipped domains x4096 biased (ragged CU-group kernel)", big, (np.arange(4096) % 5).astype(np.int32), int(150 * scale), 206 + seed_off, True)
+        campaign("d1 x4096 uniform (CU-group kernel)", big[:1], np.zeros(4096, np.int32), int(150 * scale), 207 + seed_off, False)
+        campaign("d3 x32768 biased (one wave per env)", big[2:3], np.zeros(32768, np.int32), int(20 * scale), 208 + seed_off, True)
+        sys.exit(0)
     campaign("boundary0 x4096 uniform", [boundary(0)], np.zeros(4096, np.int32), int(1000 * scale), 101, False)
     campaign("boundary0 x4096 biased", [boundary(0)], np.zeros(4096, np.int32), int(1000 * scale), 102, True)
     big = [golden_domain(x) for x in ("boundary16_biased_s2", "boundary15_biased_s5", "test1_biased_s42", "dolphine3_biased_s0", "random1_1_biased_s1", "star_biased_s6")]
