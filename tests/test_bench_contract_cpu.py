@@ -95,3 +95,21 @@ def test_algorithmic_bytes_formula_matches_survey_8d():
     # one failed step on a 30-ring: 28 * 30 + 158; one valid: + 28 * 30 + 48
     assert bench.algorithmic_bytes(1, 0, 30, 0) == 28 * 30 + 158
     assert bench.algorithmic_bytes(1, 1, 30, 30) == 56 * 30 + 206
+
+
+def test_profile_summaries_refuse_a_stale_or_foreign_library(tmp_path, monkeypatch):
+    """tools/source_state.py: a profile records the hash of the sources its library was built from; the summarisers refuse
+    a recorded hash that is not the working tree's, and a library flagged older than its sources (VERDICT r03 weak #2)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import source_state
+    now = source_state.source_hash()
+    assert len(now) == 64 and now == source_state.source_hash()
+    with pytest.raises(SystemExit, match="re-profile"):
+        source_state.check_recorded({"source_sha256": "0" * 64, "library_older_than_sources": False}, "prof_x")
+    with pytest.raises(SystemExit, match="older than its sources"):
+        source_state.check_recorded({"source_sha256": now, "library_older_than_sources": True}, "prof_x")
+    # the committed headline profile names the sources it was taken on, and a commit
+    s = json.load(open(os.path.join(ROOT, "profiles", "r04_summary.json")))
+    assert len(s["source"]["source_sha256"]) == 64 and s["source"]["library_older_than_sources"] is False
+    assert s["source"]["library_built_from"] == s["source"]["source_sha256"] and s["source"]["git_head"]
