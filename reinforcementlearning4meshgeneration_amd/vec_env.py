@@ -913,11 +913,8 @@ class SB3MeshVecEnv(MeshVecEnv, VEC_ENV_BASE):
     ``reset_tensor()`` / ``step_tensor()``.  auto_reset=False gives the reference's own DummyVecEnv variant, whose reset is
     commented out (rl/baselines/dummy_vec_env.py:49) for the evaluation callback."""
 
-    def __init__(self, *args, **kwargs):
-        kwargs.setdefault("lazy_infos", False)      # SB3's Monitor-less paths write into infos[k]: one dict per env
-        MeshVecEnv.__init__(self, *args, **kwargs)
-
-    def _finish_init(self):
+    def _finish_init(self):      # (also reached from the from_random / from_random_density constructors)
+        self.lazy_infos = False  # SB3 (VecMonitor, callbacks) writes into infos[k]: one dict per env, never a shared one
         MeshVecEnv._finish_init(self)
         if VEC_ENV_BASE is not object:
             n = self.num_envs            # VecEnv.__init__ assigns num_envs / observation_space / action_space (+ SB3 2.x bookkeeping)

@@ -146,3 +146,9 @@ def test_sb3_vecenv_contract_and_the_callbacks_save_meshes_call(rl_stack, tmp_pa
     assert dones > 0
     assert tv.get_attr("render_mode", indices=[0, 5]) == [None, None] and tv.env_is_wrapped(object) == [False] * n
     tv.close()
+    # (3) the alternative constructors build the same kind of object (BASELINE configs[4]: one generated ring per env)
+    rv = vec_env.SB3MeshVecEnv.from_random(64, 1000)
+    assert isinstance(rv, VecEnv) and rv.num_envs == 64 and rv.lazy_infos is False and rv.reset().shape == (64, 18)
+    obs, rew, done, infos = rv.step(rng.uniform([-1, -1.5, 0], [1, 1.5, 1.5], size=(64, 3)).astype(np.float32))
+    assert obs.shape == (64, 18) and len(infos) == 64 and infos[0] is not infos[1]
+    rv.close()
