@@ -54,3 +54,30 @@ def test_bench_line_states_log_capacity_scaling_and_cpu_quota():
         assert allc["cores"] == min(allc["cgroup_cpu_quota"], allc["sched_getaffinity"])
     r = line["roofline"]
     assert r["kernel"] == "meshenv::k_step_group<16, true, false, true>" and 5 < r["kernel_avg_us"] < 40 and 0 < r["frac"] < 1
+
+
+def test_two_rank_launch_as_the_driver_starts_it_gloo_rehearsal_on_one_gpu():
+    """The N > 1 launch path exactly as the driver starts it -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps 20 --warmup 5` -- rehearsed on the one GPU of this box:
+    both ranks share device 0 (MESHENV_BENCH_DEVICE=0) and the exchange goes over gloo (RCCL refuses two ranks on one device;
+    the one-rank test above covers the `nccl` backend).  Checks the rank plumbing (RANK / LOCAL_RANK / WORLD_SIZE), the env
+    sharding, the bucket exchange across two processes, the max-over-ranks timing and that rank 0 alone prints the line."""
+    env = dict(os.environ, MESHENV_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29583", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--backend", "gloo", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                      # rank 0 only
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and cfg["n_envs_per_gpu"] == 4096 and cfg["n_envs_total"] == 8192
+    assert cfg["collectives"] >= 1 and cfg["gather_every"] == 20 and "gloo all-gather" in cfg["workload"]
+    # (gloo stages every bucket through host memory and both ranks share one GPU: a plumbing rehearsal, not a rate)
+    assert line["value"] > 1e6 and abs(line["value"] - 8192 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+    # strong scaling: the same total split over the ranks
+    p = subprocess.run(cmd + ["--envs-total", "4096"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["config"]["n_envs_per_gpu"] == 2048 and line["config"]["n_envs_total"] == 4096
