@@ -36,7 +36,29 @@ env = MeshVecEnv([boundary(0)], n_envs=n); env.reset()
 acts = torch.from_numpy(a).cuda(); h = 0.0
 for t in range(T):
     o, r, d, c = env.step(acts[t]); h += float(o.double().sum()) + float(r.sum()) + float(d.sum())
-print(json.dumps(dict(valid=st["valid"], obs_mismatch=st["obs_mismatch"], kernel=env.step_kernel, checksum=h)))
+kernel0 = env.step_kernel
+env.close()
+# long rings (d1 / d2 / d3: 120 / 196 / 272 vertices): the multi-chunk pre-filters of point_inside and of the observation scan
+# against the unfiltered forms of -DMESHENV_NO_FILTERS -- CU-group kernel with ragged LDS (4096 envs) and k_step (600 envs)
+import os
+gold = os.path.join(sys.argv[1], "tests", "golden")
+doms = [[tuple(p) for p in np.load(os.path.join(gold, f + ".npz"))["domain_xy"]] for f in ("boundary16_biased_s2", "boundary15_biased_s5", "test1_biased_s42")]
+h_long, valid_long, kernels = 0.0, 0, []
+for nl in (4096, 600):
+    el = MeshVecEnv(doms, env_domain=(np.arange(nl) % 3).astype(np.int32)); el.reset()
+    kernels.append(el.step_kernel)
+    rl = np.random.default_rng(77)
+    for t in range(160):
+        al = rl.uniform([-1, -1.5, 0], [1, 1.5, 1.5], size=(nl, 3))
+        pk = rl.random(nl) < 0.6
+        bl = np.stack([rl.uniform(-1, 1, nl), rl.uniform(0.2, 1.0, nl), rl.uniform(0.3, 1.2, nl)], axis=1)
+        al[pk] = bl[pk]
+        o, r, d, c = el.step(torch.from_numpy(al.astype(np.float32)).cuda())
+        h_long += float(o.double().sum()) + float(r.sum()) + float(d.sum())
+    valid_long += el.counters()["valid"]
+    el.close()
+print(json.dumps(dict(valid=st["valid"], obs_mismatch=st["obs_mismatch"], kernel=kernel0, checksum=h,
+                      checksum_long=h_long, valid_long=valid_long, kernels_long=kernels)))
 """
 
 
@@ -64,6 +86,9 @@ def test_no_helper_and_no_filters_builds_agree_with_the_default_library():
         res = _run(_build(name, flags))
         assert res["valid"] == base["valid"] and res["obs_mismatch"] == 0, (name, res)
         assert res["checksum"] == base["checksum"], (name, res["checksum"], base["checksum"])
+        # long rings: the pre-filtered passes change nothing, to the last bit of every observation and reward
+        assert res["valid_long"] == base["valid_long"] > 20000 and res["checksum_long"] == base["checksum_long"], (name, res, base)
+    assert base["kernels_long"] == ["meshenv::k_step_group<16, true, true, false>", "meshenv::k_step<false, true, false, false>"]
 
 
 def test_dev_build_runs_the_experimental_kernels():
