@@ -32,6 +32,9 @@ def test_committed_bench_line_has_the_contract_keys():
     assert "log_capacity=0" in d["config"]["workload"] and d["config"]["log_capacity"] == 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0
     assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.5
+    # the guide's figure is the one printed as `traffic`; the calibrated and raw readings sit beside it
+    assert abs(r["traffic_over_algorithmic"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 1e-9
+    assert r["traffic_other_readings"]["raw_FETCH+WRITE"] < r["traffic_other_readings"]["calibrated"] < r["traffic"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert isinstance(c["cpu_model"], str) and c["cpu_model"] and c["fp64_transcendentals_per_env_step"]["atan2"] > 10
