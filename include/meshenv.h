@@ -179,6 +179,8 @@ int meshenv_group_size(const MeshEnv *h);
  * domains whose sixteen longest rings would not fit one CU).  5 = k_step_group<G, ., false, true>: the CU-group kernel of
  * batches whose ring stride is at most 64 slots (every ring pass is one 64-lane pass, no chunk loops).
  * 6 = k_step<false, true, false, true>: the one-wave-per-env kernel of such batches (default geometry constants).
+ * 7 / 8 = k_step<false, true, false, false | true, true>: the throughput-regime forms of 0 / 6 (batches staged record-first,
+ * from 8192 envs): a rule-0 quad with a corner that cannot be valid is rejected before the point-in-polygon pass.
  * (2 exists in -DMESHENV_DEV builds of the library only.) */
 int meshenv_step_kernel(const MeshEnv *h);
 /* The smoothing kernels evaluate `x ** 2` like the reference's libm (CPython's float ** 2 is pow(x, 2.0), which glibc does

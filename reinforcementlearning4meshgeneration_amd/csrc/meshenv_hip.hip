@@ -346,6 +346,7 @@ static int create_impl(int device, int n_domains, const int32_t *dom_offsets_hos
         CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_step<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_step<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
+        CREATE_HIP(hipFuncSetAttribute((const void *)k_step<false, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
         CREATE_HIP(hipFuncSetAttribute((const void *)k_init_domains, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsCap));
     }
@@ -852,7 +853,10 @@ int meshenv_step_kernel(const MeshEnv *h)
 {
     if (!h) return MESHENV_E_ARG;
     if (h->front_moved) return 3;
-    if (h->group <= 1) return (h->default_params && h->cap <= 64) ? 6 : 0;
+    if (h->group <= 1) {
+        const bool pre = h->default_params && (h->stage_bits & 2);
+        return h->default_params && h->cap <= 64 ? (pre ? 8 : 6) : (pre ? 7 : 0);
+    }
     if (h->spec) return 2;
     if (h->env_lds) return 4;
 #ifdef MESHENV_DEV
@@ -1230,6 +1234,10 @@ static int launch_step(MeshEnv *h, int n_steps, const float *actions_dev, float 
         ka.reward = reward_dev; ka.done = done_dev; ka.complete = complete_dev; ka.term_obs = terminal_obs_dev;              \
         ka.auto_reset = auto_reset; ka.step0 = (unsigned long long)h->steps_done;                                            \
         if (h->front_moved) hipLaunchKernelGGL((k_step<MULTI, DEF, true>), grid, block, h->lds, h->stream, ka);              \
+        else if (DEF && !MULTI && (h->stage_bits & 2) && h->cap <= 64)                                                       \
+            hipLaunchKernelGGL((k_step<false, DEF, false, DEF, DEF>), grid, block, h->lds, h->stream, ka);                   \
+        else if (DEF && !MULTI && (h->stage_bits & 2))                                                                       \
+            hipLaunchKernelGGL((k_step<false, DEF, false, false, DEF>), grid, block, h->lds, h->stream, ka);                 \
         else if (DEF && h->cap <= 64) hipLaunchKernelGGL((k_step<MULTI, DEF, false, DEF>), grid, block, h->lds, h->stream, ka); \
         else hipLaunchKernelGGL((k_step<MULTI, DEF>), grid, block, h->lds, h->stream, ka);                                   \
     } while (0)

@@ -1818,7 +1818,11 @@ __device__ __forceinline__ KStepArgs late_kstep_args()
 // (kTie: the handle has smoothed a front -- its rings hold vertices off the 1e-4 lattice and half-quantum angles, so the
 // angles take the tie-breaking atan2 of the move() path, csrc/meshenv_geom.h; the host then steps with these instantiations)
 // (kSmall: ring stride <= 64, as in step_group_body -- every ring pass is one 64-lane pass)
-template <bool kMulti, bool kDefaultParams, bool kTie = false, bool kSmall = false>
+// (kPre: the exact early rejection of a rule-0 quad before the point-in-polygon pass (env_check, pre_reject) in the ONE-step
+// kernel too.  The T-step kernel always had it; in one step per launch it is a throughput lever only -- the slowest chains of a
+// small batch are valid steps, which only pay for the test: 512 / 1024 envs +1 %, 8192 neutral, 65 536 envs -5.4 %, mixed
+// 32 768 -5.5 % (tools/ab_big.sh, tools/ab_misc.sh, round 4) -- so the host selects it together with record-first staging)
+template <bool kMulti, bool kDefaultParams, bool kTie = false, bool kSmall = false, bool kPre = false>
 __global__ void __launch_bounds__(64, MESHENV_STEP_WAVES_PER_SIMD)
 k_step(const KStepArgs A)
 {
@@ -1914,7 +1918,7 @@ k_step(const KStepArgs A)
         if (kSmall) __builtin_assume(c.n <= 64 && c.n >= 0);   // (again per iteration: an extraction / a reset has rewritten n)
         const int n_before = c.n;
         // env_step, with the keys of a ring staged without them fetched between the checks and the update
-        Decision d = env_check(c, S, a0, a1, a2, kMulti);
+        Decision d = env_check(c, S, a0, a1, a2, kMulti || kPre);
         if (d.ok) {
             if (light) load_keys(c, S);
             env_apply(c, S, d);

@@ -364,9 +364,10 @@ class MeshVecEnv:
         """Name (as rocprofv3 prints it) of the kernel the next step() launches, from meshenv_step_kernel: the CU-group kernel
         for batches of one workgroup per CU, the one-wave-per-env kernel otherwise -- in its tie-breaking instantiation
         (`k_step<false, true, true>`) between a front smoothing and the next reset of all envs."""
-        return {0: "meshenv::k_step<false, true, false, false>", 6: "meshenv::k_step<false, true, false, true>", 1: f"meshenv::k_step_group<{self.group_size}, true, false, false>",
+        return {0: "meshenv::k_step<false, true, false, false, false>", 6: "meshenv::k_step<false, true, false, true, false>",
+                7: "meshenv::k_step<false, true, false, false, true>", 8: "meshenv::k_step<false, true, false, true, true>", 1: f"meshenv::k_step_group<{self.group_size}, true, false, false>",
                 2: f"meshenv::k_step_spec<{self.group_size}, true>",
-                3: "meshenv::k_step<false, true, true, false>",
+                3: "meshenv::k_step<false, true, true, false, false>",
                 4: "meshenv::k_step_group<16, true, true, false>",
                 5: f"meshenv::k_step_group<{self.group_size}, true, false, true>"}[self._L.meshenv_step_kernel(self._handle)]
 

@@ -146,7 +146,7 @@ def test_config4_full_size_32768_mixed_envs_sampled_oracle_shadow(torch_cuda):
     n, T, S = 32768, 32, 768
     env_domain = (np.arange(n) % 3).astype(np.int32)
     env = MeshVecEnv(doms, env_domain=env_domain)
-    assert env.step_kernel == "meshenv::k_step<false, true, false, false>"
+    assert env.step_kernel == "meshenv::k_step<false, true, false, false, true>"     # throughput form: early quad rejection
     pick = np.arange(0, n, n // S)[:S] + np.arange(S) % 3          # all three domains in the sample
     pick = np.unique(np.clip(pick, 0, n - 1))
     batch = RefBatch([RefEnv.from_points(doms[env_domain[k]], cap_new=64) for k in pick])

@@ -351,7 +351,7 @@ def test_steps_after_a_front_smoothing_run_the_tie_breaking_kernel(torch_cuda):
     for j in range(S):
         code, sw, o_ref = refs[j].smooth_pave_full(400)
         assert code == 0 and sw == int(sweeps[pick[j]]) and np.array_equal(obs_after[j], o_ref.astype(np.float32)), j
-    assert L.meshenv_step_kernel(h) == 3 and env.step_kernel == "meshenv::k_step<false, true, true, false>"
+    assert L.meshenv_step_kernel(h) == 3 and env.step_kernel == "meshenv::k_step<false, true, true, false, false>"
     steps(60)
     assert differing[0] == 0
     env.reset()

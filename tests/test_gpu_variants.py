@@ -88,7 +88,7 @@ def test_no_helper_and_no_filters_builds_agree_with_the_default_library():
         assert res["checksum"] == base["checksum"], (name, res["checksum"], base["checksum"])
         # long rings: the pre-filtered passes change nothing, to the last bit of every observation and reward
         assert res["valid_long"] == base["valid_long"] > 20000 and res["checksum_long"] == base["checksum_long"], (name, res, base)
-    assert base["kernels_long"] == ["meshenv::k_step_group<16, true, true, false>", "meshenv::k_step<false, true, false, false>"]
+    assert base["kernels_long"] == ["meshenv::k_step_group<16, true, true, false>", "meshenv::k_step<false, true, false, false, false>"]
 
 
 def test_dev_build_runs_the_experimental_kernels():
