@@ -66,12 +66,27 @@ class EpisodeTools:
             raise ValueError(f"save_meshes(quality=True, type={index}): see get_quality")
         return self._vec.quad_quality(np.stack([element_xy(m) for m in meshes]), int(index))
 
-    def save_meshes(self, name, meshes, quality=False, indexing=False, type=0, dpi=300, style='k.-'):
+    @property
+    def last_generated_meshes(self):
+        """`generated_meshes` of the last FINISHED episode (kept across auto-reset: the reference's callers read the finished
+        mesh before their own reset, which an auto-resetting batch has already done for them)."""
+        ep = self._vec.get_last_episode(self._k)
+        return [ep["vertex_xy"][q] for q in ep["quads"]]
+
+    def save_meshes(self, name, meshes, quality=False, indexing=False, type=0, dpi=300, style='k.-', *, which="current"):
         """MeshGeneration.save_meshes, general/mesh.py:1785-1792: a PNG of the domain with every element edge generated so
         far (the reference draws its whole vertex graph, whatever `meshes` holds) and a label on each element of
-        `meshes`: its index (indexing), its get_quality(element, type) (quality), or both."""
+        `meshes`: its index (indexing), its get_quality(element, type) (quality), or both.  which="last" (extension, keyword
+        only) draws the graph of the archived finished episode instead -- pair it with `last_generated_meshes` under
+        auto-reset."""
         from .plotting import save_meshes
-        quads, vxy = self._vec.get_elements(self._k)
+        if which == "last":
+            ep = self._vec.get_last_episode(self._k)
+            quads, vxy = ep["quads"], ep["vertex_xy"]
+        elif which == "current":
+            quads, vxy = self._vec.get_elements(self._k)
+        else:
+            raise ValueError("which must be 'current' or 'last'")
         save_meshes(name, len(self.points), quads, vxy, meshes, quality=quality, indexing=indexing, type=type, dpi=dpi,
                     style=style, quality_of=self._quality_of)
 

@@ -146,6 +146,25 @@ def test_sb3_vecenv_contract_and_the_callbacks_save_meshes_call(rl_stack, tmp_pa
     assert dones > 0
     assert tv.get_attr("render_mode", indices=[0, 5]) == [None, None] and tv.env_is_wrapped(object) == [False] * n
     tv.close()
+    # under auto-reset the finished mesh is the ARCHIVED episode: envs[k].last_generated_meshes / save_meshes(which="last")
+    av = vec_env.SB3MeshVecEnv([boundary(0)], n_envs=64, log_capacity=256)
+    av.reset()
+    finished = None
+    for _ in range(1500):
+        a = np.stack([rng.uniform(-0.49, 0.49, 64), rng.uniform(0.2, 1.0, 64), rng.uniform(0.3, 1.2, 64)], 1).astype(np.float32)
+        _, _, done, infos = av.step(a)
+        hit = [k for k in np.nonzero(done)[0] if len(av.envs[int(k)].last_generated_meshes) > 5]   # complete or truncated
+        if hit:
+            finished = int(hit[0])
+            break
+    assert finished is not None
+    view = av.envs[finished]
+    last = view.last_generated_meshes
+    assert len(last) > 5 and len(view.generated_meshes) == 0          # the running episode has just been reset
+    path = tmp_path / "last.png"
+    view.save_meshes(str(path), meshes=last, indexing=True, style='k-', dpi=30, which="last")
+    assert path.exists() and path.stat().st_size > 1000
+    av.close()
     # (3) the alternative constructors build the same kind of object (BASELINE configs[4]: one generated ring per env)
     rv = vec_env.SB3MeshVecEnv.from_random(64, 1000)
     assert isinstance(rv, VecEnv) and rv.num_envs == 64 and rv.lazy_infos is False and rv.reset().shape == (64, 18)
